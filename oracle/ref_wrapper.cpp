@@ -1,0 +1,101 @@
+/*
+ * ref_wrapper.cpp -- C entry points around the REFERENCE's own CPU path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Built by oracle/Makefile together with
+ * /root/reference/align.cpp and /root/reference/gact.cpp, compiled unchanged
+ * from where they lie, into oracle/_ref/libdarwin_ref.so (git-ignored; never
+ * copied into this repo).  It plays the part darwin.cpp plays for those two
+ * files: it owns the globals gact.cpp declares `extern` (gact.cpp:39-46,
+ * gact.h:30-32; defined in darwin.cpp:39,65-69,82-93) and calls
+ * AlignWithBT / GACT with the caller's arguments.
+ *
+ * Used to (1) validate oracle/gact_oracle.c, (2) generate tests/golden/.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <queue>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <unistd.h>
+
+#include "align.h"   /* from /root/reference via -I */
+#include "gact.h"
+
+/* globals darwin.cpp defines for gact.cpp */
+bool same_file = false;
+std::vector<std::string> reference_seqs;
+std::vector<long long int> reference_lengths;
+std::vector<std::string> reads_seqs;
+std::vector<std::string> rev_reads_seqs;
+std::vector<long long int> reads_lengths;
+std::vector<std::vector<std::string> > reference_descrips;
+std::vector<std::vector<std::string> > reads_descrips;
+int tile_size = 320;
+int tile_overlap = 120;
+int first_tile_score_threshold = 35;
+
+extern "C" {
+
+/* AlignWithBT (align.cpp:60): queue copied front-first into out[] */
+int ref_align_with_bt(const char *ref_seq, long long ref_len,
+                      const char *query_seq, long long query_len,
+                      int match_score, int mismatch_score, int gap_open, int gap_extend,
+                      int query_pos, int ref_pos, int reverse, int first, int early_terminate,
+                      int *out, int out_cap)
+{
+    std::queue<int> q = AlignWithBT((char *)ref_seq, ref_len, (char *)query_seq, query_len,
+                                    match_score, mismatch_score, gap_open, gap_extend,
+                                    query_pos, ref_pos, reverse != 0, first != 0, early_terminate);
+    int n = 0;
+    while (!q.empty()) {
+        if (n >= out_cap) return -1;
+        out[n++] = q.front();
+        q.pop();
+    }
+    return n;
+}
+
+/*
+ * GACT (gact.cpp:48) for one candidate.  The reference prints to an ofstream;
+ * the line (or nothing) is read back into line_out.  Returns its length.
+ */
+int ref_gact(const char *ref_str, const char *query_str, int ref_length, int query_length,
+             int tile_size_, int tile_overlap_, int ref_pos, int query_pos,
+             int first_tile_score_threshold_, int ref_id, int query_id, int complement,
+             int match_score, int mismatch_score, int gap_open, int gap_extend,
+             int same_file_, const char *ref_name, const char *query_name,
+             char *line_out, int line_cap)
+{
+    same_file = same_file_ != 0;
+    if ((int)reference_descrips.size() <= ref_id) reference_descrips.resize(ref_id + 1);
+    if ((int)reads_descrips.size() <= query_id) reads_descrips.resize(query_id + 1);
+    reference_descrips[ref_id].assign(1, std::string(ref_name));
+    reads_descrips[query_id].assign(1, std::string(query_name));
+
+    char path[] = "/tmp/darwin_ref_XXXXXX";
+    int fd = mkstemp(path);
+    if (fd < 0) return -1;
+    close(fd);
+    {
+        std::ofstream fout(path);
+        GACT((char *)ref_str, (char *)query_str, ref_length, query_length,
+             tile_size_, tile_overlap_, ref_pos, query_pos, first_tile_score_threshold_,
+             ref_id, query_id, complement != 0,
+             match_score, mismatch_score, gap_open, gap_extend, fout);
+        fout.close();
+    }
+    std::ifstream fin(path);
+    std::stringstream ss;
+    ss << fin.rdbuf();
+    fin.close();
+    unlink(path);
+    const std::string s = ss.str();
+    if ((int)s.size() + 1 > line_cap) return -1;
+    memcpy(line_out, s.c_str(), s.size() + 1);
+    return (int)s.size();
+}
+
+} /* extern "C" */

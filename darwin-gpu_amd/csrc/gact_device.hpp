@@ -1,0 +1,341 @@
+// gact_device.hpp -- device side of the MI355X (gfx950) GACT engine.
+//
+// Work decomposition:
+//   * one GACT tile (<= C*16 x C*16 cells) per 16-lane group, four groups per
+//     wave64.  Lane g owns C consecutive query columns; a step of the wave
+//     advances every lane by one ref row, lane g being g rows behind lane g-1
+//     (anti-diagonal wavefront).  The three values that cross a lane boundary
+//     (M+open, D and H of the neighbour's last column) move by DPP row_shr:1,
+//     which on CDNA is exactly a shift inside a 16-lane row.
+//   * scores live in VGPRs (3*C per lane); nothing of the recurrence touches
+//     LDS or HBM.  LDS holds only the group's unpacked bases.
+//   * traceback pointers: 4 bits per cell, built from v_cmp lane masks that
+//     are merged on the scalar unit and shifted into a per-column
+//     accumulator with add-with-carry; 8 rows per dword, flushed every 8
+//     steps as 16-byte stores into a per-group HBM workspace.  Only the
+//     window the traceback can reach is produced.
+//
+// Semantics restated from the reference (bit-exact contract):
+//   recurrence / pointer / arg-max rules   align.cpp:114-183
+//   traceback                              align.cpp:185-230
+//   tile chain, rescoring, emit            gact.cpp:82-225
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gact_hip.h"
+
+namespace gact {
+
+constexpr int kGroup = 16;                 // lanes per tile
+constexpr int kGroupsPerWave = 4;
+constexpr int kNegInf = -(1 << 30);        // align.h:18
+constexpr uint32_t kRefPad = 0xFFu;        // never equals a query code
+constexpr uint32_t kQueryPad = 0xFEu;      // never equals a ref code
+constexpr int kBlockThreads = 256;
+
+struct SeqSetDev {
+    const uint32_t *packed;   // 2 bits/base, 16 bases per word, base k at bits 2*(k%16)
+    const uint8_t *raw;       // raw bytes (always resident)
+    const int64_t *offsets;   // n+1
+    int32_t n;
+    int32_t use_raw;          // 1: compare raw bytes (set holds non-ACGT)
+};
+
+struct KParams {
+    int32_t tile_size, early;
+    int32_t match, mismatch, open, ext;
+    int32_t thr;
+    int32_t ws_words;         // workspace dwords per group
+};
+
+template <int C> struct Geometry {
+    static constexpr int kTileMax = C * kGroup;
+    static constexpr int kRefLds = kGroup + kTileMax + kGroup;   // front pad + bases + tail pad
+    static constexpr int kQueryLds = kTileMax;
+    static constexpr int kGroupLds = kRefLds + kQueryLds;
+    static constexpr int kMaxSteps = kTileMax + kGroup;
+    static constexpr int kMaxFlush = (kMaxSteps + 7) / 8 + 1;
+    static constexpr int kWsWords = kMaxFlush * C * kGroup;
+};
+
+__device__ __forceinline__ int dpp_row_shr1(int v, int old)
+{
+    // lane n of each 16-lane row reads lane n-1; lane 0 keeps `old`
+    return __builtin_amdgcn_update_dpp(old, v, 0x111, 0xF, 0xF, false);
+}
+
+// x*2 + bit(lane) in one VALU op: the lane mask of a compare is the carry-in
+// of v_addc_co_u32 (hipcc does not form this from `x + x + cond`)
+__device__ __forceinline__ uint32_t shl1_insert(uint32_t x, uint64_t lane_mask)
+{
+    uint32_t r;
+    uint64_t carry_out;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(lane_mask));
+    return r;
+}
+__device__ __forceinline__ uint64_t lanes(bool cond) { return __builtin_amdgcn_ballot_w64(cond); }
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return imax(imax(a, b), c); }
+
+// value of `v` held by the first lane of group g, made wave-uniform
+__device__ __forceinline__ int group_value(int v, int g)
+{
+    return __builtin_amdgcn_readlane(v, g * kGroup);
+}
+__device__ __forceinline__ int wave_max4(int v)
+{
+    return imax(imax(group_value(v, 0), group_value(v, 1)), imax(group_value(v, 2), group_value(v, 3)));
+}
+__device__ __forceinline__ int wave_min4(int v)
+{
+    return imin(imin(group_value(v, 0), group_value(v, 1)), imin(group_value(v, 2), group_value(v, 3)));
+}
+
+// one base of a resident set at concat position pos
+__device__ __forceinline__ uint32_t fetch_base(const SeqSetDev &s, int64_t pos, bool raw)
+{
+    if (raw) return s.raw[pos];
+    const uint32_t w = s.packed[pos >> 4];
+    return (w >> ((uint32_t)(pos & 15) * 2u)) & 3u;
+}
+
+// ---------------------------------------------------------------------------
+// Tile descriptor of one group for one DP pass.
+struct GroupTile {
+    int R, Q;          // DP extent (0 => idle)
+    int first;         // arg-max wanted (align.cpp:190)
+};
+
+struct PassOut {
+    int pos_score;     // H[R][Q]                       (align.cpp:179-181)
+    int best, bi, bj;  // arg-max, group-reduced        (align.cpp:173-177)
+    int tB;            // first step whose pointers were stored
+};
+
+// ---------------------------------------------------------------------------
+// The DP pass of one wave: four tiles, one per 16-lane group.
+//
+// ref_lds points at this lane's view of the group's ref bytes so that the base
+// of DP row (t - gl) is ref_lds[t]; rows outside 1..R read the pad code.
+template <int C, bool AMAX>
+__device__ __forceinline__ void dp_pass(const KParams &kp, const int gl,
+                                        const uint8_t *__restrict__ ref_lds,
+                                        const uint32_t (&qb)[C],
+                                        const GroupTile gt, const int T_end, const int tB,
+                                        uint32_t *__restrict__ ws, PassOut &po)
+{
+    const int match = kp.match, mismatch = kp.mismatch, open = kp.open, ext = kp.ext;
+
+    int Hup[C], Mo[C], Iup[C];
+    uint32_t acc[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        Hup[c] = 0;            // H[0][j] = 0              (align.cpp:88)
+        Mo[c] = open;          // M[0][j] + gap_open       (align.cpp:89,149)
+        Iup[c] = kNegInf;      // I[0][j] = -INF           (align.cpp:90)
+        acc[c] = 0;
+    }
+    // what lane gl-1 exposes to lane gl: its last column of the row it just did
+    int Mo_last = open, D_last = kNegInf, H_last = 0;
+    int H_left_prev = 0;       // H[row-1][j0-1]
+
+    const int jbase = gl * C;                          // 0-based first column of this lane
+    const int ncol = imin(imax(gt.Q - jbase, 0), C);   // valid columns in this lane
+    const int lQ = (gt.Q > 0) ? (gt.Q - 1) / C : 0;
+    const int cQ = (gt.Q > 0) ? (gt.Q - 1) - lQ * C : 0;
+    int pos_score = 0;
+    int best = 0, bi = 0, bj = 0;                      // align.cpp:109-112
+
+    uint32_t rb = ref_lds[1];
+
+    auto step = [&](const int t, auto ptr_tag) {
+        constexpr bool PTR = decltype(ptr_tag)::value;
+        const uint32_t rb_next = ref_lds[t + 1];
+        const int row = t - gl;
+
+        const int Ml0 = dpp_row_shr1(Mo_last, open);      // M[i][0] + open, M[i][0] = 0
+        const int Dl0 = dpp_row_shr1(D_last, kNegInf);    // D[i][0] = -INF
+        const int Hl = dpp_row_shr1(H_last, 0);           // H[i][0] = 0
+        int Hd = H_left_prev;
+        H_left_prev = Hl;
+
+        int M[C];
+        // pass 1: everything that depends only on the previous row
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int sub = (qb[c] == rb) ? match : mismatch;      // align.cpp:134
+            const int Mx = Hd + sub;                                // :138-144 (max(M,I,D) == H)
+            Hd = Hup[c];
+            M[c] = imax(Mx, 0);                                     // :145-147
+            const int Ie = Iup[c] + ext;                            // ins_extend :150
+            if (PTR) acc[c] = shl1_insert(acc[c], lanes(Mo[c] >= Ie));   // :170
+            Iup[c] = imax(Mo[c], Ie);                               // :154
+            Mo[c] = M[c] + open;                                    // next row's ins_open, this row's del_open
+        }
+        // pass 2: the in-row chain through D
+        int Ml = Ml0, Dl = Dl0;
+        const bool rowvalid = (unsigned)(row - 1) < (unsigned)gt.R;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int De = Dl + ext;                                // del_extend :152
+            const int D = imax(Ml, De);                             // :156
+            const int H = imax3(M[c], Iup[c], D);                   // :158-160 (M >= 0)
+            Hup[c] = H;
+            if (PTR) {
+                // :162-168 with M>=0: ZERO iff H==0, else MATCH iff M==H, else INSERT iff I==H
+                // the three masks are merged on the scalar unit
+                const uint64_t nz = lanes(H > 0);
+                const uint64_t a = lanes(M[c] == H);
+                const uint64_t b = lanes(Iup[c] == H);
+                uint32_t x = shl1_insert(acc[c], lanes(Ml >= De));   // :171
+                x = shl1_insert(x, nz & (a | b));
+                x = shl1_insert(x, nz & (a | ~b));
+                acc[c] = x;
+            }
+            if (AMAX) {
+                // :173-177, `>=` in (i, then j) order; each lane sees its rows and
+                // columns in that order, lanes are merged afterwards
+                const bool take = (H >= best) & rowvalid & (c < ncol);
+                best = take ? H : best;
+                bi = take ? row : bi;
+                bj = take ? (jbase + c + 1) : bj;
+            }
+            Ml = Mo[c];
+            Dl = D;
+        }
+        Mo_last = Ml;
+        D_last = Dl;
+        H_last = Hup[C - 1];
+
+        if (row == gt.R && gl == lQ && gt.Q > 0) {                  // :179-181
+            int v = 0;
+#pragma unroll
+            for (int c = 0; c < C; c++) v = (c == cQ) ? Hup[c] : v;
+            pos_score = v;
+        }
+        rb = rb_next;
+    };
+
+    int t = 1;
+    for (; t < tB && t <= T_end; t++) step(t, std::false_type{});
+    uint4 *wsq = reinterpret_cast<uint4 *>(ws) + gl;
+    int k = 0;
+    for (; t <= T_end; t++, k++) {
+        step(t, std::true_type{});
+        if ((k & 7) == 7) {
+#pragma unroll
+            for (int q = 0; q < C / 4; q++)
+                wsq[q * kGroup] = make_uint4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            wsq += (C / 4) * kGroup;
+        }
+    }
+    if (k & 7) {
+        const int sh = 4 * (8 - (k & 7));
+#pragma unroll
+        for (int q = 0; q < C / 4; q++)
+            wsq[q * kGroup] = make_uint4(acc[4 * q] << sh, acc[4 * q + 1] << sh,
+                                         acc[4 * q + 2] << sh, acc[4 * q + 3] << sh);
+    }
+
+    if (AMAX) {
+        // merge the 16 lanes: largest H, then largest i, then largest j
+#pragma unroll
+        for (int m = 1; m < kGroup; m <<= 1) {
+            const int ob = __shfl_xor(best, m, kGroup);
+            const int oi = __shfl_xor(bi, m, kGroup);
+            const int oj = __shfl_xor(bj, m, kGroup);
+            const bool take = (ob > best) | ((ob == best) & ((oi > bi) | ((oi == bi) & (oj > bj))));
+            best = take ? ob : best;
+            bi = take ? oi : bi;
+            bj = take ? oj : bj;
+        }
+    }
+    po.pos_score = __shfl(pos_score, lQ, kGroup);
+    po.best = best;
+    po.bi = bi;
+    po.bj = bj;
+    po.tB = tB;
+}
+
+// ---------------------------------------------------------------------------
+// Traceback (align.cpp:185-230), run by one lane per group.
+
+template <int C>
+__device__ __forceinline__ uint32_t load_ptr(const uint32_t *ws, int i, int j, int tB)
+{
+    const int l = (j - 1) / C;
+    const int c = (j - 1) - l * C;
+    const int k = i + l - tB;
+    const uint32_t *p = ws + ((((k >> 3) * (C / 4) + (c >> 2)) * kGroup + l) << 2) + (c & 3);
+    // written by other lanes of this wave during the pass: read past the L1
+    const uint32_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (w >> (28 - 4 * (k & 7))) & 15u;
+}
+
+// Emit is called once per state, in the order AlignWithBT pushes them, with
+// the DP cell (i,j) the state was read at.
+template <int C, class Emit>
+__device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int tB, int early,
+                                          int &ref_steps, int &query_steps, Emit &&emit)
+{
+    int is = 0, js = 0;
+    int state = GACT_STATE_Z;
+    uint32_t nib = 0;
+    if (i >= 1 && j >= 1 && early > 0) {
+        nib = load_ptr<C>(ws, i, j, tB);
+        state = nib & 3;
+    }
+    while (state != GACT_STATE_Z) {
+        emit(state, i, j);
+        int next;
+        if (state == GACT_STATE_M) { next = -1; i--; j--; is++; js++; }
+        else if (state == GACT_STATE_I) { next = (nib & 8) ? GACT_STATE_M : GACT_STATE_I; i--; is++; }
+        else { next = (nib & 4) ? GACT_STATE_M : GACT_STATE_D; j--; js++; }
+        if (is >= early || js >= early) break;       // align.cpp:205
+        if (i < 1 || j < 1) break;                   // border pointers are ZERO (align.cpp:101-107)
+        nib = load_ptr<C>(ws, i, j, tB);
+        state = (next < 0) ? (int)(nib & 3) : next;
+    }
+    ref_steps = is;
+    query_steps = js;
+}
+
+// ---------------------------------------------------------------------------
+// Loads one group's tile into LDS + registers.  DP index d (0-based) of a
+// sequence maps to slice position (reverse ? len-1-d : d)  (align.cpp:130-131).
+template <int C>
+__device__ __forceinline__ void load_tile(const SeqSetDev &rs, const SeqSetDev &qs, bool raw,
+                                          int64_t rp0, int64_t qp0, int R, int Q, bool reverse,
+                                          int gl, uint8_t *ref_lds_g, uint8_t *q_lds_g,
+                                          uint32_t (&qb)[C])
+{
+    uint32_t rbv[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const int d = gl * C + c;
+        uint32_t rv = kRefPad, qv = kQueryPad;
+        if (d < R) rv = fetch_base(rs, reverse ? rp0 + (R - 1 - d) : rp0 + d, raw);
+        if (d < Q) qv = fetch_base(qs, reverse ? qp0 + (Q - 1 - d) : qp0 + d, raw);
+        rbv[c] = rv;
+        qb[c] = qv;
+    }
+    ref_lds_g[gl] = (uint8_t)kRefPad;                                        // front pad
+    ref_lds_g[kGroup + Geometry<C>::kTileMax + gl] = (uint8_t)kRefPad;       // tail pad
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        ref_lds_g[kGroup + gl * C + c] = (uint8_t)rbv[c];
+        q_lds_g[gl * C + c] = (uint8_t)qb[c];
+    }
+}
+
+}  // namespace gact

@@ -1,0 +1,558 @@
+// gact_engine.hip -- host side of the C-ABI declared in include/gact_hip.h.
+//
+// Owns all device memory: the resident read sets (2-bit packed + raw bytes),
+// per-slot streams, descriptor/result buffers and the per-group traceback
+// workspace.  Stands where cuda_host.cu stands in the reference (GPU_init,
+// Align_Batch_GPU, GPU_close) and additionally runs the whole GACT_Batch
+// state machine (gact.cpp:231-560) on the device.
+//
+// There is deliberately no CPU path in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gact_hip.h"
+#include "gact_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t err__ = (expr);                                                        \
+        if (err__ != hipSuccess)                                                          \
+            return fail(GACT_HIP_EDEVICE, "%s failed at %s:%d: %s", #expr, __FILE__,      \
+                        __LINE__, hipGetErrorString(err__));                              \
+    } while (0)
+
+struct SeqSet {
+    uint32_t *d_packed = nullptr;
+    uint8_t *d_raw = nullptr;
+    int64_t *d_offsets = nullptr;
+    std::vector<int64_t> h_offsets;
+    int32_t n = 0;
+    int64_t total = 0;
+    bool has_other = false;   // holds bytes other than A/C/G/T
+    size_t cap_bases = 0, cap_seqs = 0;
+
+    gact::SeqSetDev dev(bool use_raw) const
+    {
+        gact::SeqSetDev d;
+        d.packed = d_packed; d.raw = d_raw; d.offsets = d_offsets; d.n = n;
+        d.use_raw = use_raw ? 1 : 0;
+        return d;
+    }
+    void release()
+    {
+        if (d_packed) (void)hipFree(d_packed);
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_offsets) (void)hipFree(d_offsets);
+        d_packed = nullptr; d_raw = nullptr; d_offsets = nullptr;
+        cap_bases = cap_seqs = 0; n = 0; total = 0;
+    }
+};
+
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = std::max(n, (size_t)1024);
+        if (hipMalloc((void **)&p, want * sizeof(T)) != hipSuccess) return -1;
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    DevBuf<gact_tile> tiles;
+    DevBuf<gact_tile_result> results;
+    DevBuf<uint8_t> states;
+    DevBuf<gact_candidate> cands;
+    DevBuf<gact_overlap> overlaps;
+    int *d_counter = nullptr;
+    uint32_t *d_ws = nullptr;
+    int *d_flags = nullptr;
+    SeqSet inline_ref, inline_query;   // Align_Batch_GPU-style inline tiles
+};
+
+}  // namespace
+
+struct gact_hip_engine {
+    gact_hip_params params;
+    gact::KParams kp;
+    int C = 20;                 // columns per lane
+    hipDeviceProp_t prop;
+    int grid_blocks = 0;        // persistent grid
+    int blocks_per_cu = 0;
+    size_t ws_words_total = 0;
+    SeqSet sets[GACT_NUM_SETS];
+    std::vector<Slot> slots;
+    std::mutex upload_mu;
+};
+
+namespace {
+
+int set_device(gact_hip_engine *e)
+{
+    HIP_TRY(hipSetDevice(e->params.device_id));
+    return 0;
+}
+
+int check_slot(gact_hip_engine *e, int slot)
+{
+    if (!e) return fail(GACT_HIP_EINVAL, "engine is NULL");
+    if (slot < 0 || slot >= (int)e->slots.size())
+        return fail(GACT_HIP_EINVAL, "slot %d out of range [0,%d)", slot, (int)e->slots.size());
+    return 0;
+}
+
+// upload + pack one set on `stream`
+int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, const int64_t *offsets,
+               int32_t n_seqs)
+{
+    if (n_seqs < 0 || (n_seqs > 0 && (!offsets || !concat && offsets[n_seqs] > 0)))
+        return fail(GACT_HIP_EINVAL, "upload: bad arguments");
+    const int64_t total = n_seqs ? offsets[n_seqs] : 0;
+    if (n_seqs && offsets[0] != 0) return fail(GACT_HIP_EINVAL, "upload: offsets[0] must be 0");
+    for (int32_t k = 0; k < n_seqs; k++)
+        if (offsets[k + 1] < offsets[k]) return fail(GACT_HIP_EINVAL, "upload: offsets not monotone");
+
+    const size_t need_bases = (size_t)total + 64;
+    if (need_bases > s.cap_bases) {
+        if (s.d_raw) (void)hipFree(s.d_raw);
+        if (s.d_packed) (void)hipFree(s.d_packed);
+        s.d_raw = nullptr; s.d_packed = nullptr; s.cap_bases = 0;
+        HIP_TRY(hipMalloc((void **)&s.d_raw, need_bases));
+        HIP_TRY(hipMalloc((void **)&s.d_packed, (need_bases / 16 + 4) * sizeof(uint32_t)));
+        s.cap_bases = need_bases;
+    }
+    const size_t need_seqs = (size_t)n_seqs + 2;
+    if (need_seqs > s.cap_seqs) {
+        if (s.d_offsets) (void)hipFree(s.d_offsets);
+        s.d_offsets = nullptr; s.cap_seqs = 0;
+        HIP_TRY(hipMalloc((void **)&s.d_offsets, need_seqs * sizeof(int64_t)));
+        s.cap_seqs = need_seqs;
+    }
+    s.h_offsets.assign(offsets, offsets + n_seqs + 1);
+    if (n_seqs == 0) s.h_offsets.assign(1, 0);
+    s.n = n_seqs; s.total = total;
+
+    HIP_TRY(hipMemcpyAsync(s.d_offsets, s.h_offsets.data(), s.h_offsets.size() * sizeof(int64_t),
+                           hipMemcpyHostToDevice, sl.stream));
+    if (total) HIP_TRY(hipMemcpyAsync(s.d_raw, concat, (size_t)total, hipMemcpyHostToDevice, sl.stream));
+    HIP_TRY(hipMemsetAsync(sl.d_flags, 0, sizeof(int), sl.stream));
+    const int64_t n_words = (total + 15) / 16 + 2;
+    const int threads = 256;
+    const int blocks = (int)std::min<int64_t>((n_words + threads - 1) / threads, 4096);
+    hipLaunchKernelGGL(gact::pack_kernel, dim3(std::max(blocks, 1)), dim3(threads), 0, sl.stream,
+                       s.d_raw, total, s.d_packed, n_words, sl.d_flags);
+    HIP_TRY(hipGetLastError());
+    int flags = 0;
+    HIP_TRY(hipMemcpyAsync(&flags, sl.d_flags, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    s.has_other = (flags & 1) != 0;
+    (void)e;
+    return 0;
+}
+
+template <int C>
+int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &qf, const SeqSet &qr, int n,
+                 int states_stride)
+{
+    const bool raw = rs.has_other || qf.has_other || qr.has_other;
+    const int waves_needed = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
+    const int blocks_needed = (waves_needed + 3) / 4;
+    const int blocks = std::max(1, std::min(blocks_needed, e->grid_blocks));
+    hipLaunchKernelGGL((gact::align_tiles_kernel<C>), dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream,
+                       e->kp, rs.dev(raw), qf.dev(raw), qr.dev(raw), sl.tiles.p, n, sl.results.p,
+                       sl.states.p, states_stride, sl.d_ws);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int C>
+int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int complement, int same_file)
+{
+    const SeqSet &rs = e->sets[GACT_SET_REF];
+    const SeqSet &qs = e->sets[complement ? GACT_SET_QUERY_RC : GACT_SET_QUERY];
+    const bool raw = rs.has_other || qs.has_other;
+    const int waves_needed = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
+    const int blocks_needed = (waves_needed + 3) / 4;
+    const int blocks = std::max(1, std::min(blocks_needed, e->grid_blocks));
+    hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream,
+                       e->kp, rs.dev(raw), qs.dev(raw), sl.cands.p, first, n, complement, same_file,
+                       sl.overlaps.p, sl.d_counter, sl.d_ws);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int C> int occupancy_blocks(int *out)
+{
+    int a = 0, b = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
+    *out = std::max(1, std::min(a, b));
+    return 0;
+}
+
+int validate_tiles(gact_hip_engine *e, const SeqSet &rs, const SeqSet &qf, const SeqSet &qr, int n,
+                   const gact_tile *tiles)
+{
+    const int T = e->params.tile_size;
+    for (int t = 0; t < n; t++) {
+        const gact_tile &d = tiles[t];
+        if (d.ref_len < 0) continue;
+        const SeqSet &qs = (d.query_set == GACT_SET_QUERY_RC) ? qr : qf;
+        if (d.query_set != GACT_SET_QUERY && d.query_set != GACT_SET_QUERY_RC)
+            return fail(GACT_HIP_EINVAL, "tile %d: query_set %d", t, d.query_set);
+        if (d.ref_len > T || d.query_len > T || d.query_len < 0)
+            return fail(GACT_HIP_ERANGE, "tile %d: length %d x %d exceeds tile_size %d", t, d.ref_len,
+                        d.query_len, T);
+        if (d.ref_id < 0 || d.ref_id >= rs.n || d.query_id < 0 || d.query_id >= qs.n)
+            return fail(GACT_HIP_ERANGE, "tile %d: sequence id out of range", t);
+        const int64_t rl = rs.h_offsets[d.ref_id + 1] - rs.h_offsets[d.ref_id];
+        const int64_t ql = qs.h_offsets[d.query_id + 1] - qs.h_offsets[d.query_id];
+        if (d.ref_off < 0 || d.ref_off + (int64_t)d.ref_len > rl || d.query_off < 0 ||
+            d.query_off + (int64_t)d.query_len > ql)
+            return fail(GACT_HIP_ERANGE, "tile %d: slice outside its sequence", t);
+    }
+    return 0;
+}
+
+int run_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &qf, const SeqSet &qr, int32_t n,
+              const gact_tile *tiles, gact_tile_result *results, uint8_t *states, int32_t states_stride)
+{
+    if (n == 0) return 0;
+    if (sl.tiles.reserve(n) || sl.results.reserve(n) || sl.states.reserve((size_t)n * states_stride))
+        return fail(GACT_HIP_ENOMEM, "device allocation failed");
+    HIP_TRY(hipMemcpyAsync(sl.tiles.p, tiles, (size_t)n * sizeof(gact_tile), hipMemcpyHostToDevice, sl.stream));
+    HIP_TRY(hipMemsetAsync(sl.results.p, 0, (size_t)n * sizeof(gact_tile_result), sl.stream));
+    HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
+    int rc = (e->C == 20) ? launch_tiles<20>(e, sl, rs, qf, qr, n, states_stride)
+                          : launch_tiles<32>(e, sl, rs, qf, qr, n, states_stride);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
+    sl.timed = true;
+    HIP_TRY(hipMemcpyAsync(results, sl.results.p, (size_t)n * sizeof(gact_tile_result), hipMemcpyDeviceToHost,
+                           sl.stream));
+    HIP_TRY(hipMemcpyAsync(states, sl.states.p, (size_t)n * states_stride, hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *gact_hip_last_error(void) { return g_err.c_str(); }
+
+int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
+{
+    if (!p || !out) return fail(GACT_HIP_EINVAL, "create: NULL argument");
+    *out = nullptr;
+    if (p->tile_size < 1 || p->tile_size > GACT_HIP_MAX_TILE)
+        return fail(GACT_HIP_EINVAL, "tile_size %d not in [1,%d]", p->tile_size, GACT_HIP_MAX_TILE);
+    if (p->tile_overlap < 0 || p->tile_overlap >= p->tile_size)
+        return fail(GACT_HIP_EINVAL, "tile_overlap %d must be in [0, tile_size)", p->tile_overlap);
+    if (p->mismatch > 0 || p->gap_open > 0 || p->gap_extend > 0)
+        return fail(GACT_HIP_EINVAL, "scoring: mismatch, gap_open and gap_extend must be <= 0");
+    if (p->match < 0 || (int64_t)p->match * p->tile_size > (1 << 28) ||
+        p->mismatch < -(1 << 20) || p->gap_open < -(1 << 20) || p->gap_extend < -(1 << 20))
+        return fail(GACT_HIP_EINVAL, "scoring: values out of the int32-safe range");
+    if (p->first_tile_score_threshold < 1)
+        return fail(GACT_HIP_EINVAL, "first_tile_score_threshold must be >= 1 (the reference loops forever otherwise, gact.cpp:82)");
+    if (p->n_slots < 1 || p->n_slots > 256) return fail(GACT_HIP_EINVAL, "n_slots %d not in [1,256]", p->n_slots);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GACT_HIP_EDEVICE, "no HIP device visible: this engine has no CPU fallback");
+    if (p->device_id < 0 || p->device_id >= ndev)
+        return fail(GACT_HIP_EINVAL, "device_id %d not in [0,%d)", p->device_id, ndev);
+
+    gact_hip_engine *e = new gact_hip_engine();
+    e->params = *p;
+    int rc = set_device(e);
+    if (rc) { delete e; return rc; }
+    if (hipGetDeviceProperties(&e->prop, p->device_id) != hipSuccess) {
+        delete e;
+        return fail(GACT_HIP_EDEVICE, "hipGetDeviceProperties failed");
+    }
+    e->C = (p->tile_size <= 20 * gact::kGroup) ? 20 : 32;
+    e->kp.tile_size = p->tile_size;
+    e->kp.early = p->tile_size - p->tile_overlap;
+    e->kp.match = p->match; e->kp.mismatch = p->mismatch;
+    e->kp.open = p->gap_open; e->kp.ext = p->gap_extend;
+    e->kp.thr = p->first_tile_score_threshold;
+    e->kp.ws_words = (e->C == 20) ? gact::Geometry<20>::kWsWords : gact::Geometry<32>::kWsWords;
+
+    rc = (e->C == 20) ? occupancy_blocks<20>(&e->blocks_per_cu) : occupancy_blocks<32>(&e->blocks_per_cu);
+    if (rc) { delete e; return rc; }
+    e->grid_blocks = e->blocks_per_cu * e->prop.multiProcessorCount;
+    const size_t groups = (size_t)e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
+    e->ws_words_total = groups * (size_t)e->kp.ws_words;
+
+    e->slots.resize(p->n_slots);
+    for (auto &sl : e->slots) {
+        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
+            hipMalloc((void **)&sl.d_counter, sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&sl.d_flags, sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&sl.d_ws, e->ws_words_total * sizeof(uint32_t)) != hipSuccess) {
+            gact_hip_destroy(e);
+            return fail(GACT_HIP_ENOMEM, "slot allocation failed (workspace %zu MiB per slot)",
+                        e->ws_words_total * 4 >> 20);
+        }
+    }
+    *out = e;
+    return 0;
+}
+
+void gact_hip_destroy(gact_hip_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->params.device_id);
+    for (auto &sl : e->slots) {
+        if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+        sl.tiles.release(); sl.results.release(); sl.states.release();
+        sl.cands.release(); sl.overlaps.release();
+        sl.inline_ref.release(); sl.inline_query.release();
+        if (sl.d_counter) (void)hipFree(sl.d_counter);
+        if (sl.d_flags) (void)hipFree(sl.d_flags);
+        if (sl.d_ws) (void)hipFree(sl.d_ws);
+        if (sl.ev0) (void)hipEventDestroy(sl.ev0);
+        if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+    }
+    for (auto &s : e->sets) s.release();
+    delete e;
+}
+
+int gact_hip_get_device_info(gact_hip_engine *e, gact_hip_device_info *info)
+{
+    if (!e || !info) return fail(GACT_HIP_EINVAL, "NULL argument");
+    memset(info, 0, sizeof *info);
+    info->compute_units = e->prop.multiProcessorCount;
+    info->clock_mhz = e->prop.clockRate / 1000;
+    info->waves_per_cu = e->blocks_per_cu * (gact::kBlockThreads / 64);
+    info->wave_size = e->prop.warpSize;
+    info->hbm_bytes = (int64_t)e->prop.totalGlobalMem;
+    snprintf(info->arch, sizeof info->arch, "%s", e->prop.gcnArchName);
+    return 0;
+}
+
+int gact_hip_upload_seqs(gact_hip_engine *e, int which, const uint8_t *concat, const int64_t *offsets,
+                         int32_t n_seqs)
+{
+    if (!e) return fail(GACT_HIP_EINVAL, "engine is NULL");
+    if (which < 0 || which >= GACT_NUM_SETS) return fail(GACT_HIP_EINVAL, "which_set %d", which);
+    std::lock_guard<std::mutex> lk(e->upload_mu);
+    int rc = set_device(e);
+    if (rc) return rc;
+    return upload_set(e, e->sets[which], e->slots[0], concat, offsets, n_seqs);
+}
+
+int gact_hip_align_tiles(gact_hip_engine *e, int slot, int32_t n, const gact_tile *tiles,
+                         gact_tile_result *results, uint8_t *states, int32_t states_stride)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!tiles || !results || !states)))
+        return fail(GACT_HIP_EINVAL, "align_tiles: bad arguments");
+    if (states_stride < 2 * e->params.tile_size)
+        return fail(GACT_HIP_EINVAL, "states_stride %d < 2*tile_size", states_stride);
+    if ((rc = set_device(e))) return rc;
+    const SeqSet &rs = e->sets[GACT_SET_REF], &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
+    if ((rc = validate_tiles(e, rs, qf, qr, n, tiles))) return rc;
+    return run_tiles(e, e->slots[slot], rs, qf, qr, n, tiles, results, states, states_stride);
+}
+
+int gact_hip_align_tiles_inline(gact_hip_engine *e, int slot, int32_t n, const uint8_t *ref_bases,
+                                const uint8_t *query_bases, int32_t seq_stride, const int32_t *ref_lens,
+                                const int32_t *query_lens, const uint8_t *reverses, const uint8_t *firsts,
+                                gact_tile_result *results, uint8_t *states, int32_t states_stride)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!ref_bases || !query_bases || !ref_lens || !query_lens || !reverses || !firsts ||
+                            !results || !states)))
+        return fail(GACT_HIP_EINVAL, "align_tiles_inline: bad arguments");
+    if (states_stride < 2 * e->params.tile_size)
+        return fail(GACT_HIP_EINVAL, "states_stride %d < 2*tile_size", states_stride);
+    if (n == 0) return 0;
+    if ((rc = set_device(e))) return rc;
+    Slot &sl = e->slots[slot];
+    // gather the slices into two temporary resident sets
+    std::vector<int64_t> roff(n + 1, 0), qoff(n + 1, 0);
+    std::vector<gact_tile> tiles(n);
+    for (int t = 0; t < n; t++) {
+        const int rl = ref_lens[t] < 0 ? 0 : ref_lens[t];
+        const int ql = (ref_lens[t] < 0 || query_lens[t] < 0) ? 0 : query_lens[t];
+        if (rl > seq_stride || ql > seq_stride) return fail(GACT_HIP_ERANGE, "tile %d longer than seq_stride", t);
+        roff[t + 1] = roff[t] + rl;
+        qoff[t + 1] = qoff[t] + ql;
+        gact_tile &d = tiles[t];
+        d.ref_id = t; d.query_id = t; d.ref_off = 0; d.query_off = 0;
+        d.ref_len = ref_lens[t] < 0 ? -1 : rl; d.query_len = ql;
+        d.reverse = reverses[t]; d.first = firsts[t]; d.query_set = GACT_SET_QUERY; d.pad = 0;
+    }
+    std::vector<uint8_t> rcat((size_t)roff[n]), qcat((size_t)qoff[n]);
+    for (int t = 0; t < n; t++) {
+        memcpy(rcat.data() + roff[t], ref_bases + (size_t)t * seq_stride, (size_t)(roff[t + 1] - roff[t]));
+        memcpy(qcat.data() + qoff[t], query_bases + (size_t)t * seq_stride, (size_t)(qoff[t + 1] - qoff[t]));
+    }
+    if ((rc = upload_set(e, sl.inline_ref, sl, rcat.data(), roff.data(), n))) return rc;
+    if ((rc = upload_set(e, sl.inline_query, sl, qcat.data(), qoff.data(), n))) return rc;
+    if ((rc = validate_tiles(e, sl.inline_ref, sl.inline_query, sl.inline_query, n, tiles.data()))) return rc;
+    return run_tiles(e, sl, sl.inline_ref, sl.inline_query, sl.inline_query, n, tiles.data(), results, states,
+                     states_stride);
+}
+
+int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const gact_candidate *cands)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !cands)) return fail(GACT_HIP_EINVAL, "candidates_upload: bad arguments");
+    if ((rc = set_device(e))) return rc;
+    Slot &sl = e->slots[slot];
+    const SeqSet &rs = e->sets[GACT_SET_REF];
+    const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
+    const int32_t qn = std::max(qf.n, qr.n);
+    for (int32_t k = 0; k < n; k++) {
+        const gact_candidate &c = cands[k];
+        if (c.ref_id < 0 || c.ref_id >= rs.n || c.query_id < 0 || c.query_id >= qn)
+            return fail(GACT_HIP_ERANGE, "candidate %d: sequence id out of range", k);
+        const int64_t rl = rs.h_offsets[c.ref_id + 1] - rs.h_offsets[c.ref_id];
+        // darwin.cpp:222-224 clamps ref_pos to the read length; positions beyond
+        // the reads would make GACT slice outside them
+        if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0)
+            return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
+    }
+    if (sl.cands.reserve(n) || sl.overlaps.reserve(n)) return fail(GACT_HIP_ENOMEM, "device allocation failed");
+    if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, cands, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
+                                  sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    return 0;
+}
+
+int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n, int complement,
+                                  int same_file)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    Slot &sl = e->slots[slot];
+    if (first < 0 || n < 0 || (size_t)first + (size_t)n > sl.cands.cap)
+        return fail(GACT_HIP_EINVAL, "candidates_run: range [%d,%d) not uploaded", first, first + n);
+    if ((rc = set_device(e))) return rc;
+    const SeqSet &qs = e->sets[complement ? GACT_SET_QUERY_RC : GACT_SET_QUERY];
+    if (n > 0 && (e->sets[GACT_SET_REF].n == 0 || qs.n == 0))
+        return fail(GACT_HIP_EINVAL, "candidates_run: read sets not uploaded");
+    HIP_TRY(hipMemsetAsync(sl.d_counter, 0, sizeof(int), sl.stream));
+    HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
+    if (n > 0) {
+        rc = (e->C == 20) ? launch_extend<20>(e, sl, first, n, complement, same_file)
+                          : launch_extend<32>(e, sl, first, n, complement, same_file);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
+    sl.timed = true;
+    return 0;
+}
+
+int gact_hip_candidates_run(gact_hip_engine *e, int slot, int32_t n, int complement, int same_file)
+{
+    return gact_hip_candidates_run_range(e, slot, 0, n, complement, same_file);
+}
+
+int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_overlap *out)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    Slot &sl = e->slots[slot];
+    if (n < 0 || (size_t)n > sl.overlaps.cap || (n > 0 && !out))
+        return fail(GACT_HIP_EINVAL, "candidates_fetch: bad arguments");
+    if ((rc = set_device(e))) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(out, sl.overlaps.p, (size_t)n * sizeof(gact_overlap), hipMemcpyDeviceToHost,
+                                  sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    return 0;
+}
+
+int gact_hip_extend_candidates(gact_hip_engine *e, int slot, int32_t n, const gact_candidate *cands,
+                               int complement, int same_file, gact_overlap *out)
+{
+    int rc = gact_hip_candidates_upload(e, slot, n, cands);
+    if (rc) return rc;
+    if ((rc = gact_hip_candidates_run(e, slot, n, complement, same_file))) return rc;
+    return gact_hip_candidates_fetch(e, slot, n, out);
+}
+
+int gact_hip_sync(gact_hip_engine *e, int slot)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if ((rc = set_device(e))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->slots[slot].stream));
+    return 0;
+}
+
+int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if (!ms) return fail(GACT_HIP_EINVAL, "ms is NULL");
+    Slot &sl = e->slots[slot];
+    if (!sl.timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
+    if ((rc = set_device(e))) return rc;
+    HIP_TRY(hipEventSynchronize(sl.ev1));
+    HIP_TRY(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
+    return 0;
+}
+
+void *gact_hip_device_overlaps(gact_hip_engine *e, int slot)
+{
+    if (check_slot(e, slot)) return nullptr;
+    return e->slots[slot].overlaps.p;
+}
+
+void *gact_hip_stream(gact_hip_engine *e, int slot)
+{
+    if (check_slot(e, slot)) return nullptr;
+    return (void *)e->slots[slot].stream;
+}
+
+int gact_hip_format_overlap(const gact_overlap *o, const char *ref_name, const char *query_name, char *buf,
+                            int32_t cap)
+{
+    if (!o || !ref_name || !query_name || !buf || cap <= 0) return fail(GACT_HIP_EINVAL, "format: bad arguments");
+    // exact bytes of gact.cpp:214-224
+    return snprintf(buf, (size_t)cap, "ref_id: %s, query_id: %s, ab: %d, ae: %d, bb: %d, be: %d, score: %d, comp: %d\n",
+                    ref_name, query_name, o->ab, o->ae, o->bb, o->be, o->score, o->comp);
+}
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+"""ctypes binding of the C-ABI in include/gact_hip.h (libgact_hip.so).
+
+Plumbing only: numpy arrays in, numpy arrays out.  Fails loudly when the HIP
+library is missing or no device is present -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # darwin-gpu_amd/
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in
+           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp")] + \
+          [os.path.join(_ROOT, "include", "gact_hip.h")]
+
+SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2
+STATE_Z, STATE_D, STATE_I, STATE_M = 0, 1, 2, 3
+
+TILE_DTYPE = np.dtype([("ref_id", "<i4"), ("query_id", "<i4"), ("ref_off", "<i4"), ("query_off", "<i4"),
+                       ("ref_len", "<i4"), ("query_len", "<i4"),
+                       ("reverse", "u1"), ("first", "u1"), ("query_set", "u1"), ("pad", "u1")])
+TILE_RESULT_DTYPE = np.dtype([(n, "<i4") for n in
+                              ("score", "max_i", "max_j", "ref_steps", "query_steps", "n_states")])
+CAND_DTYPE = np.dtype([(n, "<i4") for n in ("ref_id", "query_id", "ref_pos", "query_pos")])
+OVERLAP_DTYPE = np.dtype([(n, "<i4") for n in
+                          ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted",
+                           "first_tile_score", "n_tiles", "reserved")] + [("cells", "<i8")])
+assert TILE_DTYPE.itemsize == 28 and OVERLAP_DTYPE.itemsize == 56
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("tile_size", "tile_overlap", "match", "mismatch", "gap_open", "gap_extend",
+                 "first_tile_score_threshold", "device_id", "n_slots", "reserved")]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("compute_units", C.c_int32), ("clock_mhz", C.c_int32), ("waves_per_cu", C.c_int32),
+                ("wave_size", C.c_int32), ("hbm_bytes", C.c_int64), ("arch", C.c_char * 32)]
+
+
+class GactHipError(RuntimeError):
+    pass
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> darwin-gpu_amd/libgact_hip.so (in-tree)."""
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in SOURCES)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(_ROOT, "include"), "-o", LIB_PATH, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GactHipError("%s is missing: run __graft_entry__.build() (hipcc) first; "
+                           "this engine has no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.gact_hip_last_error.restype = C.c_char_p
+    L.gact_hip_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.gact_hip_destroy.argtypes = [vp]
+    L.gact_hip_destroy.restype = None
+    L.gact_hip_get_device_info.argtypes = [vp, C.POINTER(DeviceInfo)]
+    L.gact_hip_upload_seqs.argtypes = [vp, C.c_int, vp, vp, i32]
+    L.gact_hip_align_tiles.argtypes = [vp, C.c_int, i32, vp, vp, vp, i32]
+    L.gact_hip_align_tiles_inline.argtypes = [vp, C.c_int, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32]
+    L.gact_hip_extend_candidates.argtypes = [vp, C.c_int, i32, vp, C.c_int, C.c_int, vp]
+    L.gact_hip_candidates_upload.argtypes = [vp, C.c_int, i32, vp]
+    L.gact_hip_candidates_run.argtypes = [vp, C.c_int, i32, C.c_int, C.c_int]
+    L.gact_hip_candidates_run_range.argtypes = [vp, C.c_int, i32, i32, C.c_int, C.c_int]
+    L.gact_hip_candidates_fetch.argtypes = [vp, C.c_int, i32, vp]
+    L.gact_hip_sync.argtypes = [vp, C.c_int]
+    L.gact_hip_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.gact_hip_device_overlaps.argtypes = [vp, C.c_int]
+    L.gact_hip_device_overlaps.restype = vp
+    L.gact_hip_stream.argtypes = [vp, C.c_int]
+    L.gact_hip_stream.restype = vp
+    L.gact_hip_format_overlap.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
+    for name in ("create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
+                 "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range",
+                 "candidates_fetch", "sync", "last_kernel_ms", "format_overlap"):
+        getattr(L, "gact_hip_" + name).restype = C.c_int
+    _lib = L
+    return L
+
+
+EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_hip_get_device_info",
+           "gact_hip_upload_seqs", "gact_hip_align_tiles", "gact_hip_align_tiles_inline",
+           "gact_hip_extend_candidates", "gact_hip_candidates_upload", "gact_hip_candidates_run",
+           "gact_hip_candidates_run_range", "gact_hip_candidates_fetch", "gact_hip_sync",
+           "gact_hip_last_kernel_ms", "gact_hip_device_overlaps", "gact_hip_stream",
+           "gact_hip_format_overlap")
+
+
+class Engine:
+    """One gact_hip_engine.  Mirrors GPU_init .. GPU_close of the reference."""
+
+    def __init__(self, tile_size=320, tile_overlap=120, scoring=(1, -1, -1, -1), threshold=35,
+                 device_id=0, n_slots=1):
+        self.L = load()
+        self.p = Params(tile_size, tile_overlap, scoring[0], scoring[1], scoring[2], scoring[3],
+                        threshold, device_id, n_slots, 0)
+        self.h = C.c_void_p()
+        self._check(self.L.gact_hip_create(C.byref(self.p), C.byref(self.h)))
+        self.tile_size = tile_size
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GactHipError("gact_hip error %d: %s" % (rc, self.L.gact_hip_last_error().decode()))
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.gact_hip_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        info = DeviceInfo()
+        self._check(self.L.gact_hip_get_device_info(self.h, C.byref(info)))
+        return {"compute_units": info.compute_units, "clock_mhz": info.clock_mhz,
+                "waves_per_cu": info.waves_per_cu, "wave_size": info.wave_size,
+                "hbm_bytes": info.hbm_bytes, "arch": info.arch.decode()}
+
+    def upload(self, which, concat, offsets):
+        concat = np.ascontiguousarray(concat, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self._check(self.L.gact_hip_upload_seqs(self.h, which, concat.ctypes.data, offsets.ctypes.data,
+                                                len(offsets) - 1))
+
+    def upload_seqs(self, which, seqs):
+        seqs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else
+                np.asarray(s, dtype=np.uint8) for s in seqs]
+        offs = np.zeros(len(seqs) + 1, dtype=np.int64)
+        if seqs:
+            offs[1:] = np.cumsum([len(s) for s in seqs])
+        cat = np.concatenate(seqs) if seqs else np.zeros(0, np.uint8)
+        self.upload(which, cat, offs)
+
+    def align_tiles(self, tiles, slot=0):
+        tiles = np.ascontiguousarray(tiles, dtype=TILE_DTYPE)
+        n = len(tiles)
+        stride = 2 * self.tile_size
+        res = np.zeros(n, dtype=TILE_RESULT_DTYPE)
+        states = np.zeros((n, stride), dtype=np.uint8)
+        self._check(self.L.gact_hip_align_tiles(self.h, slot, n, tiles.ctypes.data, res.ctypes.data,
+                                                states.ctypes.data, stride))
+        return res, states
+
+    def align_tiles_inline(self, refs, queries, reverses, firsts, slot=0):
+        n = len(refs)
+        stride_seq = max([1] + [len(r) for r in refs] + [len(q) for q in queries])
+        rb = np.zeros((n, stride_seq), dtype=np.uint8)
+        qb = np.zeros((n, stride_seq), dtype=np.uint8)
+        rl = np.zeros(n, dtype=np.int32)
+        ql = np.zeros(n, dtype=np.int32)
+        for t in range(n):
+            r = np.frombuffer(refs[t], dtype=np.uint8) if isinstance(refs[t], (bytes, bytearray)) else refs[t]
+            q = np.frombuffer(queries[t], dtype=np.uint8) if isinstance(queries[t], (bytes, bytearray)) else queries[t]
+            rb[t, :len(r)] = r
+            qb[t, :len(q)] = q
+            rl[t], ql[t] = len(r), len(q)
+        rv = np.ascontiguousarray(reverses, dtype=np.uint8)
+        fs = np.ascontiguousarray(firsts, dtype=np.uint8)
+        stride = 2 * self.tile_size
+        res = np.zeros(n, dtype=TILE_RESULT_DTYPE)
+        states = np.zeros((n, stride), dtype=np.uint8)
+        self._check(self.L.gact_hip_align_tiles_inline(
+            self.h, slot, n, rb.ctypes.data, qb.ctypes.data, stride_seq, rl.ctypes.data, ql.ctypes.data,
+            rv.ctypes.data, fs.ctypes.data, res.ctypes.data, states.ctypes.data, stride))
+        return res, states
+
+    def extend(self, cands, complement=False, same_file=True, slot=0):
+        cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        out = np.zeros(len(cands), dtype=OVERLAP_DTYPE)
+        self._check(self.L.gact_hip_extend_candidates(self.h, slot, len(cands), cands.ctypes.data,
+                                                      int(complement), int(same_file), out.ctypes.data))
+        return out
+
+    def candidates_upload(self, cands, slot=0):
+        cands = np.ascontiguousarray(cands, dtype=CAND_DTYPE)
+        self._check(self.L.gact_hip_candidates_upload(self.h, slot, len(cands), cands.ctypes.data))
+
+    def candidates_run(self, n, complement=False, same_file=True, slot=0, first=0):
+        self._check(self.L.gact_hip_candidates_run_range(self.h, slot, first, n, int(complement), int(same_file)))
+
+    def candidates_fetch(self, n, slot=0):
+        out = np.zeros(n, dtype=OVERLAP_DTYPE)
+        self._check(self.L.gact_hip_candidates_fetch(self.h, slot, n, out.ctypes.data))
+        return out
+
+    def sync(self, slot=0):
+        self._check(self.L.gact_hip_sync(self.h, slot))
+
+    def last_kernel_ms(self, slot=0):
+        ms = C.c_float()
+        self._check(self.L.gact_hip_last_kernel_ms(self.h, slot, C.byref(ms)))
+        return float(ms.value)
+
+    def device_overlaps_ptr(self, slot=0):
+        return self.L.gact_hip_device_overlaps(self.h, slot)
+
+    def format_overlap(self, rec, ref_name, query_name):
+        rec = np.ascontiguousarray(rec, dtype=OVERLAP_DTYPE)
+        buf = C.create_string_buffer(512)
+        n = self._check(self.L.gact_hip_format_overlap(rec.ctypes.data, ref_name.encode(), query_name.encode(),
+                                                       buf, 512))
+        return buf.raw[:n].decode()
+
+
+def queue_from_tile(result, states, first):
+    """The std::queue<int> AlignWithBT would return (align.cpp:190-199), as a list."""
+    n = int(result["n_states"])
+    st = [int(x) for x in states[:n]]
+    if first:
+        return [int(result["score"]), int(result["max_i"]), int(result["max_j"])] + st
+    return [int(result["score"])] + st

@@ -1,0 +1,201 @@
+/*
+ * gact_hip.h -- C-ABI of the MI355X-native GACT tiled-alignment engine.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch
+ * types.  Each entry point names the reference interface it stands under
+ * (file:line in Tongdongq/darwin-gpu); the C++ shim that keeps the
+ * reference's own gact.h / align.h signatures on top of it is
+ * darwin-gpu_amd/host/, and INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative GACT_HIP_E* code on
+ *     failure; gact_hip_last_error() returns the calling thread's message.
+ *     (The reference has no return codes: cudaSafeCall prints and exit(-1)s,
+ *     cuda_header.h:309-319; the shim reproduces that.)
+ *   - `slot` is the feeder-thread index the reference passes around as a
+ *     GPU_storage (gact.h:51-67, darwin.cpp:625): each slot owns a HIP stream
+ *     and its buffers, so N host threads may call concurrently with N
+ *     different slots.
+ *   - caller owns every host buffer; the engine owns all device memory.
+ *   - there is no CPU fallback: without a usable gfx950 device
+ *     gact_hip_create fails.
+ */
+#ifndef GACT_HIP_H
+#define GACT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GACT_HIP_OK          0
+#define GACT_HIP_EINVAL     -1   /* bad argument / unsupported parameter   */
+#define GACT_HIP_EDEVICE    -2   /* HIP runtime error                      */
+#define GACT_HIP_ENOMEM     -3
+#define GACT_HIP_ERANGE     -4   /* descriptor points outside a sequence   */
+
+#define GACT_HIP_MAX_TILE   512  /* largest tile_size the kernels are built for */
+
+/* traceback states, align.h:23 */
+#define GACT_STATE_Z 0
+#define GACT_STATE_D 1   /* '-' in ref, consumes a query base (gact.cpp:126-130) */
+#define GACT_STATE_I 2   /* '-' in query, consumes a ref base (gact.cpp:121-125) */
+#define GACT_STATE_M 3
+
+/* which resident sequence set a descriptor addresses */
+#define GACT_SET_REF       0   /* reference_seqs   (gact.cpp:40) */
+#define GACT_SET_QUERY     1   /* reads_seqs       (gact.cpp:42) */
+#define GACT_SET_QUERY_RC  2   /* rev_reads_seqs   (gact.cpp:43) */
+#define GACT_NUM_SETS      3
+
+typedef struct gact_hip_engine gact_hip_engine;
+
+/*
+ * Replaces the argument list of GPU_init (gact.h:85-87, cuda_host.cu:193-237)
+ * plus the globals gact.cpp reads (gact.h:25-32): params.cfg values.
+ * Scoring domain: mismatch <= 0, gap_open <= 0, gap_extend <= 0 (the
+ * reference's traceback reads out of bounds otherwise, align.cpp:211-226).
+ */
+typedef struct {
+    int32_t tile_size;                  /* params.cfg GACT_extend.tile_size   (<= GACT_HIP_MAX_TILE) */
+    int32_t tile_overlap;               /* early_terminate = tile_size - tile_overlap, gact.cpp:94 */
+    int32_t match, mismatch, gap_open, gap_extend;
+    int32_t first_tile_score_threshold; /* gact.cpp:107 */
+    int32_t device_id;                  /* reference hard-wires 0, cuda_host.cu:195 */
+    int32_t n_slots;                    /* = num_threads of GPU_init */
+    int32_t reserved;
+} gact_hip_params;
+
+/* GPU_init: cuda_host.cu:193-237 */
+int gact_hip_create(const gact_hip_params *params, gact_hip_engine **out);
+/* GPU_close: cuda_host.cu:239-258 */
+void gact_hip_destroy(gact_hip_engine *e);
+const char *gact_hip_last_error(void);
+
+/* device facts used by the measurement harness (rocminfo values) */
+typedef struct {
+    int32_t compute_units;
+    int32_t clock_mhz;
+    int32_t waves_per_cu;     /* resident waves per CU of the DP kernel */
+    int32_t wave_size;
+    int64_t hbm_bytes;
+    char    arch[32];
+} gact_hip_device_info;
+int gact_hip_get_device_info(gact_hip_engine *e, gact_hip_device_info *info);
+
+/*
+ * Makes a read set resident in HBM (replaces the per-batch substr + interleave
+ * + 2 H2D copies + gasal_pack_kernel of gact.cpp:400-407, cuda_host.cu:85-169
+ * and cuda_header.h:47-90).  `concat` holds n_seqs sequences back to back,
+ * sequence s = concat[offsets[s] .. offsets[s+1]).  Bytes may be ASCII
+ * (CPU build) or the GPU build's 0..3 recode (A0 C1 T2 G3, darwin.cpp:320-332).
+ * Bases are kept 2 bits each, 16 per uint32, when every byte is one of
+ * A/C/G/T (or 0..3); a set holding anything else (N, lower case) is also kept
+ * as raw bytes and aligned by raw byte equality like align.cpp:134.
+ */
+int gact_hip_upload_seqs(gact_hip_engine *e, int which_set,
+                         const uint8_t *concat, const int64_t *offsets, int32_t n_seqs);
+
+/* ---- per-tile batch: what Align_Batch_GPU does (cuda_host.cu:23-190) ---- */
+
+/*
+ * One tile = one AlignWithBT call (align.cpp:60-63).  The tile slices are
+ * ref[ref_off, ref_off+ref_len) of sequence ref_id in GACT_SET_REF and
+ * query[query_off, ...) of sequence query_id in `query_set`.
+ * `reverse` and `first` have AlignWithBT's meaning (align.cpp:130: reverse
+ * reads the slice back to front).  NOTE Align_Batch_GPU's reverses[] has the
+ * opposite sense (cuda_host.cu:92-142 byte-reverses when reverses[t]==0);
+ * the shim flips it.
+ */
+typedef struct {
+    int32_t ref_id, query_id;
+    int32_t ref_off, query_off;
+    int32_t ref_len, query_len;      /* 0..tile_size; ref_len < 0 marks an idle slot (cuda_host.cu:70) */
+    uint8_t reverse, first, query_set, pad;
+} gact_tile;
+
+/* out[0..4] of the reference's per-tile int block (cuda_header.h:254-302) */
+typedef struct {
+    int32_t score;        /* first ? max_score : pos_score  (align.cpp:190-199) */
+    int32_t max_i, max_j; /* 1-based arg-max, first tiles only, else 0 */
+    int32_t ref_steps;    /* i_steps of align.cpp:187 (ref bases consumed)   */
+    int32_t query_steps;  /* j_steps (query bases consumed)                  */
+    int32_t n_states;
+} gact_tile_result;
+
+/*
+ * Aligns n tiles.  states receives, for tile t, n_states bytes (GACT_STATE_*)
+ * at states + t*states_stride, in traceback order (the order AlignWithBT
+ * pushes them).  states_stride must be >= 2*tile_size.
+ */
+int gact_hip_align_tiles(gact_hip_engine *e, int slot, int32_t n, const gact_tile *tiles,
+                         gact_tile_result *results, uint8_t *states, int32_t states_stride);
+
+/*
+ * Same, with the tile slices passed inline like Align_Batch_GPU's
+ * std::vector<std::string> arguments: tile t's ref bytes at
+ * ref_bases + t*seq_stride (ref_lens[t] of them), likewise query.
+ */
+int gact_hip_align_tiles_inline(gact_hip_engine *e, int slot, int32_t n,
+                                const uint8_t *ref_bases, const uint8_t *query_bases,
+                                int32_t seq_stride,
+                                const int32_t *ref_lens, const int32_t *query_lens,
+                                const uint8_t *reverses, const uint8_t *firsts,
+                                gact_tile_result *results, uint8_t *states, int32_t states_stride);
+
+/* ---- per-candidate batch: what GACT / GACT_Batch do (gact.cpp:48-560) ---- */
+
+/* the seed hit darwin.cpp:216-238 turns into a GACT_call */
+typedef struct {
+    int32_t ref_id, query_id, ref_pos, query_pos;
+} gact_candidate;
+
+/* one record per candidate, same order as the input */
+typedef struct {
+    int32_t ref_id, query_id;
+    int32_t ab, ae, bb, be;     /* gact.cpp:219-222 */
+    int32_t score;              /* total_score, gact.cpp:197-210 */
+    int32_t comp;
+    int32_t emitted;            /* 1 iff gact.cpp:213 would print the line */
+    int32_t first_tile_score;
+    int32_t n_tiles;            /* AlignWithBT-equivalents executed */
+    int32_t reserved;
+    int64_t cells;              /* sum of ref_len*query_len over those tiles */
+} gact_overlap;
+
+/*
+ * Extends n candidates to overlaps on the device: the whole tile chain of
+ * GACT (gact.cpp:82-195), the rescoring (gact.cpp:197-210) and the emit test
+ * (gact.cpp:213) run inside one persistent kernel; no host round trip per
+ * tile.  complement selects GACT_SET_QUERY_RC as darwin.cpp:279 does.
+ */
+int gact_hip_extend_candidates(gact_hip_engine *e, int slot, int32_t n,
+                               const gact_candidate *cands, int complement, int same_file,
+                               gact_overlap *out);
+
+/* the same in three steps so a harness can time the device part alone with
+ * the inputs already resident in HBM */
+int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const gact_candidate *cands);
+int gact_hip_candidates_run(gact_hip_engine *e, int slot, int32_t n, int complement, int same_file);
+int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_overlap *out);
+/* runs on candidates [first, first+n) of the uploaded array (multi-GPU shards) */
+int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n,
+                                  int complement, int same_file);
+
+int gact_hip_sync(gact_hip_engine *e, int slot);
+/* HIP-event time of the last kernel launched on this slot's stream, in ms */
+int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);
+/* device address of the slot's gact_overlap array (for an RCCL gather) */
+void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);
+/* the slot's hipStream_t as an opaque pointer */
+void *gact_hip_stream(gact_hip_engine *e, int slot);
+
+/* formats the exact bytes of gact.cpp:214-224 */
+int gact_hip_format_overlap(const gact_overlap *o, const char *ref_name, const char *query_name,
+                            char *buf, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GACT_HIP_H */

@@ -1,0 +1,87 @@
+"""GPU parity, candidate level: the persistent HIP chain kernel vs the oracle's
+GACT restatement -- offsets, score, emit flag, tile and cell counts, bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted",
+          "first_tile_score", "n_tiles", "cells")
+
+
+def _compare(got, want, tag=""):
+    for name in FIELDS:
+        if not np.array_equal(got[name], want[name]):
+            bad = int(np.flatnonzero(got[name] != want[name])[0])
+            raise AssertionError("%s field %s differs at candidate %d:\n hip=%s\n ora=%s" %
+                                 (tag, name, bad, got[bad], want[bad]))
+
+
+def _run(rs, cf, cr, oracle, scoring=(1, -1, -1, -1), tile=320, overlap=120, thr=35, same_file=True):
+    from gact_amd import engine
+    eng = engine.Engine(tile_size=tile, tile_overlap=overlap, scoring=scoring, threshold=thr)
+    cat, offs = rs.concat(); rcat, roffs = rs.concat(rc=True)
+    eng.upload(engine.SET_REF, cat, offs)
+    eng.upload(engine.SET_QUERY, cat, offs)
+    eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+    total = 0
+    for comp, cands, qcat, qoffs in ((False, cf, cat, offs), (True, cr, rcat, roffs)):
+        if len(cands) == 0:
+            continue
+        got = eng.extend(cands, complement=comp, same_file=same_file)
+        want, _ = oracle.gact_many(cat, offs, qcat, qoffs, cands, complement=comp, same_file=same_file,
+                                   tile_size=tile, tile_overlap=overlap, threshold=thr, scoring=scoring,
+                                   n_threads=8)
+        _compare(got, want, "comp=%d" % comp)
+        total += len(cands)
+    eng.close()
+    return total
+
+
+def test_chain_small(oracle):
+    from gact_amd import synth
+    rs = synth.simulate_reads(30000, n_reads=24, seed=5, mean_len=5000, sd_len=1500, min_len=800, max_len=9000)
+    cf, cr = synth.synth_candidates(rs, seed=3, min_overlap=300)
+    assert _run(rs, cf, cr, oracle) > 100
+
+
+@pytest.mark.parametrize("scoring", [(2, -3, -5, -2), (5, -4, -10, -1), (1, -1, -2, -1)])
+def test_chain_other_scoring(oracle, scoring):
+    from gact_amd import synth
+    rs = synth.simulate_reads(20000, n_reads=16, seed=8, mean_len=4000, sd_len=1000, min_len=800, max_len=8000)
+    cf, cr = synth.synth_candidates(rs, seed=9, min_overlap=300)
+    _run(rs, cf, cr, oracle, scoring=scoring)
+
+
+@pytest.mark.parametrize("tile,overlap,thr", [(320, 120, 35), (128, 32, 20), (200, 100, 35), (320, 200, 60)])
+def test_chain_other_geometry(oracle, tile, overlap, thr):
+    from gact_amd import synth
+    rs = synth.simulate_reads(15000, n_reads=12, seed=21, mean_len=3000, sd_len=800, min_len=800, max_len=6000)
+    cf, cr = synth.synth_candidates(rs, seed=22, min_overlap=300)
+    _run(rs, cf, cr, oracle, tile=tile, overlap=overlap, thr=thr)
+
+
+def test_chain_edge_candidates(oracle):
+    """seeds at read starts/ends, pos 0, pos == len, false hits, N-containing reads"""
+    from gact_amd import synth
+    rs = synth.simulate_reads(9000, n_reads=10, seed=31, mean_len=2500, sd_len=700, min_len=400, max_len=5000,
+                              n_frac=0.01)
+    cf, cr = synth.synth_candidates(rs, seed=32, min_overlap=200, false_frac=0.3)
+    extra = []
+    for ri in range(rs.n):
+        for qi in range(rs.n):
+            L, M = len(rs.reads[ri]), len(rs.reads[qi])
+            for rp, qp in ((0, 0), (L, M - 1), (L, 0), (0, M - 1), (L // 2, M // 2), (1, 1), (L - 1, M - 1)):
+                extra.append((ri, qi, rp, max(qp, 0)))
+    extra = np.array(extra, dtype=synth.CAND_DTYPE)
+    _run(rs, np.concatenate([cf, extra]), np.concatenate([cr, extra]), oracle)
+    _run(rs, np.concatenate([cf, extra]), cr, oracle, same_file=False)
+
+
+def test_chain_pacbio_shape(oracle):
+    """~10 kb PacBio-shape reads, the shape the metric is quoted on"""
+    from gact_amd import synth
+    rs = synth.simulate_reads(120000, coverage=6, seed=41)
+    cf, cr = synth.synth_candidates(rs, seed=42)
+    n = _run(rs, cf, cr, oracle)
+    assert n > 300

@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- GACT GCUPS on synthetic PacBio-shape reads (BASELINE.json metric).
+
+One step = one pass of the hot path over the rank's shard of candidates:
+forward-strand candidates and reverse-complement candidates through the
+persistent HIP chain kernel (reads and candidates already resident in HBM),
+overlap records back on the host, and for N>1 one RCCL gather of the records
+to rank 0.  value = DP cells of all ranks / max-over-ranks time (GCUPS).
+
+N>1 is launched by the driver as
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "darwin-gpu_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+OPS_PER_CELL = 24            # 11 score + 10 pointer + 3 arg-max int32 ops
+# int32 VALU issues 64 lanes per CU per clock on gfx950 (4 SIMDs x 16 lanes: a wave64
+# v_add_u32 / v_max_i32 takes 4 cycles; measured by gact_hip_measure_valu_rate).
+# The 157.3 TFLOP/s fp32 figure of MI355X_MICROARCH.md is 2 flop x 128 lanes and does not
+# apply to integer add/max/compare.
+NOMINAL_LANES_PER_CU_CLK = 64
+
+
+def host_cores():
+    """cores this process may really use: cgroup quota if set, else the affinity mask"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ecoli10x")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even at N=1")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or args.force_dist
+    if world != args.gpus and world > 1:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    torch = dist = None
+    if use_dist:
+        # torch first: its bundled HIP runtime must be the one the process binds
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import numpy as np
+    from gact_amd import engine, workload
+
+    # ---- workload: one genome block per rank, read sets replicated everywhere
+    t_gen = time.time()
+    blk = workload.make_block(args.workload, block=rank)
+    blocks_reads = [blk.rs.reads]
+    blocks_cf, blocks_cr = [blk.cf], [blk.cr]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (blk.rs.reads, blk.cf, blk.cr))
+        blocks_reads = [g[0] for g in gathered]
+        blocks_cf = [g[1] for g in gathered]
+        blocks_cr = [g[2] for g in gathered]
+    reads, cf_all, cr_all = [], [], []
+    base = 0
+    for rd, cf, cr in zip(blocks_reads, blocks_cf, blocks_cr):
+        for c, dst in ((cf, cf_all), (cr, cr_all)):
+            c = c.copy()
+            c["ref_id"] += base
+            c["query_id"] += base
+            dst.append(c)
+        reads.extend(rd)
+        base += len(rd)
+    cf_all = np.concatenate(cf_all)
+    cr_all = np.concatenate(cr_all)
+    my_cf = workload.shard(cf_all, rank, world)
+    my_cr = workload.shard(cr_all, rank, world)
+    from gact_amd import synth
+    offs = np.zeros(len(reads) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    cat = np.concatenate(reads)
+    rcat = np.concatenate([synth.revcomp(r) for r in reads])
+    t_gen = time.time() - t_gen
+
+    eng = engine.Engine(device_id=local_rank, n_slots=1)
+    info = eng.device_info()
+    eng.upload(engine.SET_REF, cat, offs)
+    eng.upload(engine.SET_QUERY, cat, offs)
+    eng.upload(engine.SET_QUERY_RC, rcat, offs)
+    # forward-strand candidates first, reverse-complement ones after (one launch walks both)
+    nf, nr = len(my_cf), len(my_cr)
+    eng.candidates_upload(np.concatenate([my_cf, my_cr]), slot=0)
+
+    def barrier():
+        eng.sync(0)
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    kernel_ms = []
+
+    def step(record_ms=False):
+        eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=0)
+        rec = eng.candidates_fetch(nf + nr, slot=0)
+        rf, rr = rec[:nf], rec[nf:]
+        if record_ms:
+            kernel_ms.append(eng.last_kernel_ms(0))
+        gathered = None
+        if use_dist:
+            # the one collective of the path: gather of fixed-size overlap records
+            mine = np.concatenate([rf, rr]).view(np.uint8).reshape(-1, engine.OVERLAP_DTYPE.itemsize)
+            counts = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+            dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device="cuda"))
+            mx = int(max(int(c.item()) for c in counts))
+            buf = torch.zeros((mx, mine.shape[1]), dtype=torch.uint8, device="cuda")
+            buf[:mine.shape[0]] = torch.from_numpy(mine).cuda()
+            outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+            dist.gather(buf, outs, dst=0)
+            if rank == 0:
+                gathered = [o[:int(c.item())].cpu().numpy().view(engine.OVERLAP_DTYPE).reshape(-1)
+                            for o, c in zip(outs, counts)]
+        return rf, rr, gathered
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rf, rr, gathered = step(record_ms=True)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    my_cells = int(rf["cells"].sum() + rr["cells"].sum())
+    my_tiles = int(rf["n_tiles"].sum() + rr["n_tiles"].sum())
+    tot_cells, max_dt = my_cells, dt
+    if use_dist:
+        v = torch.tensor([float(my_cells), float(my_tiles)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v)
+        tot_cells, tot_tiles = int(v[0].item()), int(v[1].item())
+        m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        max_dt = float(m.item())
+    else:
+        tot_tiles = my_tiles
+
+    if rank == 0:
+        gcups = tot_cells * args.steps / max_dt / 1e9
+        # dominant kernel: extend_kernel; HIP events on its own stream, this rank
+        k_ms = float(np.mean(kernel_ms))
+        achieved_tops = OPS_PER_CELL * my_cells / (k_ms * 1e-3) / 1e12
+        measured_rate = eng.measure_valu_rate()
+        peak_tops = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
+        roofline = {
+            "bound": "valu", "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 3),
+            "unit": "TOP/s (int32 lane-ops, 24 per DP cell)", "frac": round(achieved_tops / peak_tops, 4),
+            "traffic": None,
+            "kernel": "extend_kernel", "kernel_ms": round(float(k_ms), 3),
+            "measured_valu_peak_tops": round(measured_rate / 1e12, 3),
+            "frac_of_measured_peak": round(achieved_tops / (measured_rate / 1e12), 4),
+            "peak_gcups": round(peak_tops * 1e3 / OPS_PER_CELL, 1),
+            "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
+            "waves_per_cu": info["waves_per_cu"],
+        }
+        out = {
+            "metric": "GACT GCUPS (DP cells/s) on ~10 kb PacBio-shape reads",
+            "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(max_dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": args.workload + "_self_overlap", "tile_size": 320, "tile_overlap": 120,
+                       "scoring": "+1/-1/-1/-1", "reads": len(reads), "bases": int(offs[-1]),
+                       "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles,
+                       "cells_per_step": tot_cells, "parallelism": "candidates dealt round-robin over %d GPU(s)" % world,
+                       "arch": info["arch"], "gen_seconds": round(t_gen, 1)},
+            "roofline": roofline,
+        }
+        if gathered is not None:
+            out["config"]["gathered_records"] = int(sum(len(g) for g in gathered))
+
+        if not args.no_cpu:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    eng.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr):
+    """The oracle (CPU restatement, kind "port") timed on this box's host cores on a
+    bounded sample of the same candidates; the same sample is the parity gate."""
+    import numpy as np
+    import oracle_py
+    orc = oracle_py.Oracle()
+    threads = host_cores()
+    # calibrate on a small slice, then size the sample for ~cpu_seconds
+    probe = min(len(my_cf), 4 * threads)
+    t = time.perf_counter()
+    _, cells = orc.gact_many(cat, offs, cat, offs, my_cf[:probe], complement=False, same_file=True, n_threads=threads)
+    rate = cells / max(time.perf_counter() - t, 1e-6)
+    mean_cells = max(cells / max(probe, 1), 1.0)
+    n = int(min(len(my_cf), max(probe, args.cpu_seconds * rate / mean_cells)))
+    t = time.perf_counter()
+    want, cells = orc.gact_many(cat, offs, cat, offs, my_cf[:n], complement=False, same_file=True, n_threads=threads)
+    dt = time.perf_counter() - t
+    fields = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted",
+              "first_tile_score", "n_tiles", "cells")
+    ok = all(np.array_equal(rf[f][:n], want[f]) for f in fields)
+    nr = min(len(my_cr), max(16, n // 8))
+    want_r, _ = orc.gact_many(cat, offs, rcat, offs, my_cr[:nr], complement=True, same_file=True, n_threads=threads)
+    ok = ok and all(np.array_equal(rr[f][:nr], want_r[f]) for f in fields)
+    if not ok:
+        raise SystemExit("bench.py: PARITY FAILURE between the HIP engine and the oracle on the sample")
+    base = {"value": round(cells / dt / 1e9, 4), "unit": "GCUPS", "cores": threads, "kind": "port",
+            "sample": "%d forward-strand candidates of this workload (%d cells, %.1f s), oracle/gact_oracle.c, "
+                      "%d threads over contiguous candidate ranges" % (n, cells, dt, threads)}
+    return base, {"checked_candidates": int(n + nr), "bit_exact": True}
+
+
+if __name__ == "__main__":
+    main()

@@ -197,16 +197,17 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
 }
 
 template <int C>
-int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int complement, int same_file)
+int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, int same_file)
 {
     const SeqSet &rs = e->sets[GACT_SET_REF];
-    const SeqSet &qs = e->sets[complement ? GACT_SET_QUERY_RC : GACT_SET_QUERY];
-    const bool raw = rs.has_other || qs.has_other;
+    const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
+    const bool need_f = first < rc_from, need_r = first + n > rc_from;
+    const bool raw = rs.has_other || (need_f && qf.has_other) || (need_r && qr.has_other);
     const int waves_needed = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
     const int blocks_needed = (waves_needed + 3) / 4;
     const int blocks = std::max(1, std::min(blocks_needed, e->grid_blocks));
     hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream,
-                       e->kp, rs.dev(raw), qs.dev(raw), sl.cands.p, first, n, complement, same_file,
+                       e->kp, rs.dev(raw), qf.dev(raw), qr.dev(raw), sl.cands.p, first, n, rc_from, same_file,
                        sl.overlaps.p, sl.d_counter, sl.d_ws);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -450,7 +451,9 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
         const int64_t rl = rs.h_offsets[c.ref_id + 1] - rs.h_offsets[c.ref_id];
         // darwin.cpp:222-224 clamps ref_pos to the read length; positions beyond
         // the reads would make GACT slice outside them
-        if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0)
+        const SeqSet &qv = (c.query_id < qf.n) ? qf : qr;
+        const int64_t ql = qv.h_offsets[c.query_id + 1] - qv.h_offsets[c.query_id];
+        if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0 || c.query_pos > ql)
             return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
     }
     if (sl.cands.reserve(n) || sl.overlaps.reserve(n)) return fail(GACT_HIP_ENOMEM, "device allocation failed");
@@ -460,7 +463,7 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
     return 0;
 }
 
-int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n, int complement,
+int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, int32_t n, int32_t rc_from,
                                   int same_file)
 {
     int rc = check_slot(e, slot);
@@ -469,19 +472,26 @@ int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, i
     if (first < 0 || n < 0 || (size_t)first + (size_t)n > sl.cands.cap)
         return fail(GACT_HIP_EINVAL, "candidates_run: range [%d,%d) not uploaded", first, first + n);
     if ((rc = set_device(e))) return rc;
-    const SeqSet &qs = e->sets[complement ? GACT_SET_QUERY_RC : GACT_SET_QUERY];
-    if (n > 0 && (e->sets[GACT_SET_REF].n == 0 || qs.n == 0))
+    const bool need_f = first < rc_from, need_r = first + n > rc_from;
+    if (n > 0 && (e->sets[GACT_SET_REF].n == 0 || (need_f && e->sets[GACT_SET_QUERY].n == 0) ||
+                  (need_r && e->sets[GACT_SET_QUERY_RC].n == 0)))
         return fail(GACT_HIP_EINVAL, "candidates_run: read sets not uploaded");
     HIP_TRY(hipMemsetAsync(sl.d_counter, 0, sizeof(int), sl.stream));
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
     if (n > 0) {
-        rc = (e->C == 20) ? launch_extend<20>(e, sl, first, n, complement, same_file)
-                          : launch_extend<32>(e, sl, first, n, complement, same_file);
+        rc = (e->C == 20) ? launch_extend<20>(e, sl, first, n, rc_from, same_file)
+                          : launch_extend<32>(e, sl, first, n, rc_from, same_file);
         if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
     sl.timed = true;
     return 0;
+}
+
+int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n, int complement,
+                                  int same_file)
+{
+    return gact_hip_candidates_run_mixed(e, slot, first, n, complement ? 0 : 0x7fffffff, same_file);
 }
 
 int gact_hip_candidates_run(gact_hip_engine *e, int slot, int32_t n, int complement, int same_file)
@@ -544,6 +554,36 @@ void *gact_hip_stream(gact_hip_engine *e, int slot)
 {
     if (check_slot(e, slot)) return nullptr;
     return (void *)e->slots[slot].stream;
+}
+
+int gact_hip_measure_valu_rate(gact_hip_engine *e, double *lane_ops_per_s)
+{
+    if (!e || !lane_ops_per_s) return fail(GACT_HIP_EINVAL, "NULL argument");
+    int rc = set_device(e);
+    if (rc) return rc;
+    Slot &sl = e->slots[0];
+    const int iters = 4096;
+    const int blocks = e->prop.multiProcessorCount * 8;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        HIP_TRY(hipEventRecord(a, sl.stream));
+        hipLaunchKernelGGL(gact::valu_probe_kernel, dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream, iters,
+                           12345 + rep, sl.d_flags);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b, sl.stream));
+        HIP_TRY(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        if (rep > 0 && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    const double ops = (double)blocks * gact::kBlockThreads * (double)iters * 16.0 * 2.0;
+    *lane_ops_per_s = ops / (best * 1e-3);
+    return 0;
 }
 
 int gact_hip_format_overlap(const gact_overlap *o, const char *ref_name, const char *query_name, char *buf,

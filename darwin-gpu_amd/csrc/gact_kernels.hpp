@@ -151,14 +151,15 @@ struct ChainState {
     int have_left, left_first_gap;
     int open_flag;                // right phase: the reference's `open`
     int n_tiles;
+    int comp;                     // candidate aligns against the reverse-complemented query set
     int64_t cells;
 };
 
 template <int C>
 __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
-    KParams kp, SeqSetDev refs, SeqSetDev qs,
+    KParams kp, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     const gact_candidate *__restrict__ cands, int first_cand, int n,
-    int complement, int same_file,
+    int rc_from, int same_file,
     gact_overlap *__restrict__ out, int *__restrict__ counter,
     uint32_t *__restrict__ ws_all)
 {
@@ -171,10 +172,11 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
     uint8_t *q_lds_g = ref_lds_g + G::kRefLds;
     const uint8_t *ref_lds_lane = ref_lds_g + (kGroup - 1 - w.gl);
     uint32_t *ws = ws_all + (size_t)w.slot * kp.ws_words;
-    const bool raw = refs.use_raw | qs.use_raw;
+    const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
     const int tile = kp.tile_size;
 
     ChainState s;
+    s.comp = 0;
     s.cand = -1; s.phase = 2;
     bool exhausted = false;
 
@@ -193,11 +195,13 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
                 if (idx >= n) { exhausted = true; break; }
                 const gact_candidate c = cands[first_cand + idx];
                 s.cand = first_cand + idx;
+                s.comp = (s.cand >= rc_from) ? 1 : 0;      // darwin.cpp:279 passes rev_reads_char
+                const SeqSetDev &cq = s.comp ? qrc : qfwd;
                 s.ref_id = c.ref_id; s.query_id = c.query_id;
                 s.rbase = refs.offsets[c.ref_id];
-                s.qbase = qs.offsets[c.query_id];
+                s.qbase = cq.offsets[c.query_id];
                 s.ref_len = (int)(refs.offsets[c.ref_id + 1] - s.rbase);
-                s.query_len = (int)(qs.offsets[c.query_id + 1] - s.qbase);
+                s.query_len = (int)(cq.offsets[c.query_id + 1] - s.qbase);
                 s.ref_pos = c.ref_pos; s.query_pos = c.query_pos;
                 s.rev_ref_pos = c.ref_pos; s.rev_query_pos = c.query_pos;   // gact.cpp:72-73
                 s.abpos = 0; s.bbpos = 0;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
                         gact_overlap o;
                         o.ref_id = s.ref_id; o.query_id = s.query_id;
                         o.ab = s.abpos; o.ae = s.ref_pos; o.bb = s.bbpos; o.be = s.query_pos;
-                        o.score = s.score; o.comp = complement ? 1 : 0;
+                        o.score = s.score; o.comp = s.comp;
                         o.emitted = (!(same_file && s.ref_id == s.query_id) && s.score > 0) ? 1 : 0;  // :213
                         o.first_tile_score = s.first_tile_score;
                         o.n_tiles = s.n_tiles; o.reserved = 0; o.cells = s.cells;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
         if (!have_tile) { gt.R = 0; gt.Q = 0; gt.first = 0; }
 
         uint32_t qb[C];
-        load_tile<C>(refs, qs, raw, rp0, qp0, gt.R, gt.Q, reverse, w.gl, ref_lds_g, q_lds_g, qb);
+        load_tile<C>(refs, s.comp ? qrc : qfwd, raw, rp0, qp0, gt.R, gt.Q, reverse, w.gl, ref_lds_g, q_lds_g, qb);
         wave_sync();
 
         const int T_end = wave_max4(last_step<C>(gt.R, gt.Q));
@@ -376,6 +380,29 @@ __global__ void pack_kernel(const uint8_t *__restrict__ raw, int64_t n_bases,
         packed[wi] = word;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+}
+
+
+// ---------------------------------------------------------------------------
+// Integer-VALU issue-rate probe: 16 independent v_add_u32 / v_max_i32 chains
+// per lane, nothing else.  Gives the measured int32 lane-op/s ceiling the
+// roofline fraction in bench.py is priced against.
+__global__ __launch_bounds__(kBlockThreads) void valu_probe_kernel(int iters, int seed, int *__restrict__ sink)
+{
+    int a[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = seed + k + threadIdx.x;
+    const int inc = seed | 1;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            asm volatile("v_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %2" : "+v"(a[k]) : "v"(inc), "v"(seed));
+        }
+    }
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) r ^= a[k];
+    if (r == 0x7fffffff) sink[0] = r;
 }
 
 }  // namespace gact

@@ -84,6 +84,7 @@ def load():
     L.gact_hip_candidates_upload.argtypes = [vp, C.c_int, i32, vp]
     L.gact_hip_candidates_run.argtypes = [vp, C.c_int, i32, C.c_int, C.c_int]
     L.gact_hip_candidates_run_range.argtypes = [vp, C.c_int, i32, i32, C.c_int, C.c_int]
+    L.gact_hip_candidates_run_mixed.argtypes = [vp, C.c_int, i32, i32, i32, C.c_int]
     L.gact_hip_candidates_fetch.argtypes = [vp, C.c_int, i32, vp]
     L.gact_hip_sync.argtypes = [vp, C.c_int]
     L.gact_hip_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
@@ -91,9 +92,11 @@ def load():
     L.gact_hip_device_overlaps.restype = vp
     L.gact_hip_stream.argtypes = [vp, C.c_int]
     L.gact_hip_stream.restype = vp
+    L.gact_hip_measure_valu_rate.argtypes = [vp, C.POINTER(C.c_double)]
+    L.gact_hip_measure_valu_rate.restype = C.c_int
     L.gact_hip_format_overlap.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
     for name in ("create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
-                 "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range",
+                 "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range", "candidates_run_mixed",
                  "candidates_fetch", "sync", "last_kernel_ms", "format_overlap"):
         getattr(L, "gact_hip_" + name).restype = C.c_int
     _lib = L
@@ -103,9 +106,9 @@ def load():
 EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_hip_get_device_info",
            "gact_hip_upload_seqs", "gact_hip_align_tiles", "gact_hip_align_tiles_inline",
            "gact_hip_extend_candidates", "gact_hip_candidates_upload", "gact_hip_candidates_run",
-           "gact_hip_candidates_run_range", "gact_hip_candidates_fetch", "gact_hip_sync",
+           "gact_hip_candidates_run_range", "gact_hip_candidates_run_mixed", "gact_hip_candidates_fetch", "gact_hip_sync",
            "gact_hip_last_kernel_ms", "gact_hip_device_overlaps", "gact_hip_stream",
-           "gact_hip_format_overlap")
+           "gact_hip_measure_valu_rate", "gact_hip_format_overlap")
 
 
 class Engine:
@@ -205,6 +208,10 @@ class Engine:
     def candidates_run(self, n, complement=False, same_file=True, slot=0, first=0):
         self._check(self.L.gact_hip_candidates_run_range(self.h, slot, first, n, int(complement), int(same_file)))
 
+    def candidates_run_mixed(self, n, rc_from, same_file=True, slot=0, first=0):
+        """candidates [first, first+n) of the uploaded array; index >= rc_from => complement"""
+        self._check(self.L.gact_hip_candidates_run_mixed(self.h, slot, first, n, rc_from, int(same_file)))
+
     def candidates_fetch(self, n, slot=0):
         out = np.zeros(n, dtype=OVERLAP_DTYPE)
         self._check(self.L.gact_hip_candidates_fetch(self.h, slot, n, out.ctypes.data))
@@ -217,6 +224,11 @@ class Engine:
         ms = C.c_float()
         self._check(self.L.gact_hip_last_kernel_ms(self.h, slot, C.byref(ms)))
         return float(ms.value)
+
+    def measure_valu_rate(self):
+        v = C.c_double()
+        self._check(self.L.gact_hip_measure_valu_rate(self.h, C.byref(v)))
+        return float(v.value)
 
     def device_overlaps_ptr(self, slot=0):
         return self.L.gact_hip_device_overlaps(self.h, slot)

@@ -183,6 +183,12 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
 int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n,
                                   int complement, int same_file);
 
+/* one launch over both strands: uploaded candidates with index >= rc_from are
+ * the reverse-complement ones (GACT_calls_rev of darwin.cpp:266-277), the rest
+ * forward (GACT_calls_for, :227-238) */
+int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, int32_t n,
+                                  int32_t rc_from, int same_file);
+
 int gact_hip_sync(gact_hip_engine *e, int slot);
 /* HIP-event time of the last kernel launched on this slot's stream, in ms */
 int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);
@@ -190,6 +196,10 @@ int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);
 /* the slot's hipStream_t as an opaque pointer */
 void *gact_hip_stream(gact_hip_engine *e, int slot);
+
+/* measurement aid: sustained int32 VALU lane-ops/s of this device (add/max
+ * chains, no memory), the ceiling roofline fractions are priced against */
+int gact_hip_measure_valu_rate(gact_hip_engine *e, double *lane_ops_per_s);
 
 /* formats the exact bytes of gact.cpp:214-224 */
 int gact_hip_format_overlap(const gact_overlap *o, const char *ref_name, const char *query_name,

@@ -1,0 +1,70 @@
+"""CPU suite: the C-ABI library loads and exports every symbol include/gact_hip.h declares;
+struct layouts seen from Python match the header; no compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "gact_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gact_hip_[a-z_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported(hip_lib_path):
+    from gact_amd import engine
+    lib = ctypes.CDLL(hip_lib_path)
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(engine.EXPORTS)
+
+
+def test_struct_layouts():
+    from gact_amd import engine
+    assert engine.TILE_DTYPE.itemsize == 28
+    assert engine.TILE_RESULT_DTYPE.itemsize == 24
+    assert engine.CAND_DTYPE.itemsize == 16
+    assert engine.OVERLAP_DTYPE.itemsize == 56 and engine.OVERLAP_DTYPE.fields["cells"][1] == 48
+    assert ctypes.sizeof(engine.Params) == 40
+
+
+def test_create_fails_loudly_without_a_device(hip_lib_path):
+    """no CPU fallback: without a GPU gact_hip_create must fail with a message"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present")
+    from gact_amd import engine
+    try:
+        engine.Engine()
+    except engine.GactHipError as e:
+        assert "error" in str(e)
+    else:
+        raise AssertionError("Engine() succeeded without a device")
+
+
+def test_format_overlap_matches_reference_line(hip_lib_path, oracle):
+    from gact_amd import engine
+    lib = engine.load()
+    rec = np.zeros(1, dtype=engine.OVERLAP_DTYPE)
+    rec[0] = (3, 4, 0, 3412, 3671, 7056, 2744, 1, 1, 50, 40, 0, 123)
+    buf = ctypes.create_string_buffer(512)
+    n = lib.gact_hip_format_overlap(rec.ctypes.data, b"S19_12255_5176", b"S24_8690_6836", buf, 512)
+    line = buf.raw[:n].decode()
+    assert line == "ref_id: S19_12255_5176, query_id: S24_8690_6836, ab: 0, ae: 3412, bb: 3671, be: 7056, score: 2744, comp: 1\n"
+
+
+def test_product_never_touches_the_oracle():
+    """the shipped path must not import, link or call anything under oracle/"""
+    pkg = os.path.join(ROOT, "darwin-gpu_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_py" not in txt and "gact_oracle" not in txt and "liboracle" not in txt, f

@@ -60,6 +60,26 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+DRIVER_PATH = os.path.join(_PKG, "host", "darwin_hip")
+DRIVER_SOURCES = [os.path.join(_PKG, "host", f) for f in ("darwin_hip.cpp", "gact_shim.cpp", "gact.h", "align.h")]
+
+
+def build_driver(force=False, verbose=False):
+    """g++ -> darwin-gpu_amd/host/darwin_hip: the darwin.cpp-shaped driver + the gact.h/align.h shim"""
+    build(force=force, verbose=verbose)
+    if not force and os.path.exists(DRIVER_PATH):
+        newest = max(os.path.getmtime(s) for s in DRIVER_SOURCES + [LIB_PATH])
+        if os.path.getmtime(DRIVER_PATH) >= newest:
+            return DRIVER_PATH
+    cmd = ["g++", "-O2", "-std=c++14", "-pthread", "-I" + os.path.join(_ROOT, "include"),
+           "-I" + os.path.join(_PKG, "host"), "-o", DRIVER_PATH, DRIVER_SOURCES[0], DRIVER_SOURCES[1],
+           "-L" + _PKG, "-lgact_hip", "-Wl,-rpath," + _PKG]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DRIVER_PATH
+
+
 _lib = None
 
 

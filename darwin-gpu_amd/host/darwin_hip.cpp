@@ -1,0 +1,255 @@
+// darwin_hip.cpp -- a darwin.cpp-shaped driver around the GACT shim.
+//
+//   darwin_hip <REF.fasta> <READS.fasta> CPU_THREADS --candidates FILE [--params params.cfg]
+//
+// Plays the part of reference darwin.cpp:451-646 for the GACT stage: owns the
+// globals gact.cpp reads, loads params.cfg and the two FASTA files, builds the
+// reverse complements (darwin.cpp:110-147), GPU_init, fans candidates out over
+// feeder threads (contiguous ranges, darwin.cpp:619-629), each thread calling
+// GACT_Batch for its forward and then its reverse-complement calls
+// (darwin.cpp:429-433) into darwin.<thread>.out, GPU_close.
+//
+// The D-SOFT filter is outside this path: candidates come
+// from FILE, int32 records {ref_id, query_id, ref_pos, query_pos, comp}.
+//
+//   darwin_hip --selftest FILE   exercises AlignWithBT / Align_Batch_GPU / GACT
+//                                on the cases in FILE and prints what they return.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "align.h"
+#include "gact.h"
+
+// ---- the globals of darwin.cpp:39-93 that gact.cpp / the shim read
+bool same_file = false;
+int NUM_BLOCKS = 32, THREADS_PER_BLOCK = 64, BATCH_SIZE = 2048;
+int match_score = 1, mismatch_score = -1, gap_open = -1, gap_extend = -1;
+int first_tile_score_threshold = 35;
+int tile_size = 320, tile_overlap = 120;
+int num_threads = 1;
+std::vector<long long int> reference_lengths, reads_lengths;
+std::vector<std::string> reference_seqs, reads_seqs, rev_reads_seqs;
+std::vector<std::vector<std::string> > reference_descrips, reads_descrips;
+
+static std::string rev_comp(const std::string &seq)
+{
+    std::string rc;
+    rc.reserve(seq.size());
+    for (size_t k = seq.size(); k-- > 0;) {
+        switch (seq[k]) {                       // darwin.cpp:122-142
+            case 'a': rc += 't'; break; case 'A': rc += 'T'; break;
+            case 'c': rc += 'g'; break; case 'C': rc += 'G'; break;
+            case 'g': rc += 'c'; break; case 'G': rc += 'C'; break;
+            case 't': rc += 'a'; break; case 'T': rc += 'A'; break;
+            case 'n': rc += 'n'; break; case 'N': rc += 'N'; break;
+            default: std::cerr << "Bad Nt char: " << seq[k] << std::endl; exit(1);
+        }
+    }
+    return rc;
+}
+
+// header fields split on anything but [A-Za-z0-9_] (fasta.cpp:19-33); field 0 is the printed name
+static std::vector<std::string> split_header(const std::string &h)
+{
+    std::vector<std::string> out;
+    std::string cur;
+    for (char c : h) {
+        const bool ok = (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || (c >= '0' && c <= '9') || c == '_';
+        if (ok) cur += c;
+        else if (!cur.empty()) { out.push_back(cur); cur.clear(); }
+    }
+    if (!cur.empty()) out.push_back(cur);
+    if (out.empty()) out.push_back("");
+    return out;
+}
+
+static void parse_fasta(const std::string &path, std::vector<std::vector<std::string> > &descrips,
+                        std::vector<std::string> &seqs, std::vector<long long int> &lengths)
+{
+    std::ifstream in(path);
+    if (!in) { fprintf(stderr, "cannot open %s\n", path.c_str()); exit(1); }
+    std::string line, cur;
+    bool have = false;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            if (have) { seqs.push_back(cur); lengths.push_back((long long)cur.size()); }
+            descrips.push_back(split_header(line.substr(1)));
+            cur.clear(); have = true;
+        } else if (have) {
+            cur += line;
+        }
+    }
+    if (have) { seqs.push_back(cur); lengths.push_back((long long)cur.size()); }
+}
+
+// [section] key = value, '#' / ';' comments (ConfigFile.cpp:30-56); values through atof (Chameleon.cpp:89-91)
+static std::map<std::string, double> parse_cfg(const std::string &path)
+{
+    std::map<std::string, double> kv;
+    std::ifstream in(path);
+    std::string line, section;
+    while (std::getline(in, line)) {
+        const size_t a = line.find_first_not_of(" \t\r");
+        if (a == std::string::npos) continue;
+        if (line[a] == '#' || line[a] == ';') continue;
+        if (line[a] == '[') { section = line.substr(a + 1, line.find(']') - a - 1); continue; }
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        std::string key = line.substr(a, eq - a), val = line.substr(eq + 1);
+        key.erase(key.find_last_not_of(" \t") + 1);
+        kv[section + "/" + key] = atof(val.c_str());
+    }
+    return kv;
+}
+
+struct Cand { int ref_id, query_id, ref_pos, query_pos, comp; };
+
+static void feeder(int cpu_id, const std::vector<Cand> *all, size_t lo, size_t hi, GPU_storage s)
+{
+    std::ofstream fout("darwin." + std::to_string(cpu_id) + ".out");
+    std::vector<GACT_call> calls_for, calls_rev;
+    for (size_t k = lo; k < hi; k++) {
+        const Cand &c = (*all)[k];
+        GACT_call g;                                  // darwin.cpp:227-238
+        g.ref_id = c.ref_id; g.query_id = c.query_id;
+        g.ref_pos = c.ref_pos; g.query_pos = c.query_pos;
+        g.ref_bpos = c.ref_pos; g.query_bpos = c.query_pos;
+        g.score = 0; g.first_tile_score = 0; g.first = 1; g.reverse = 1;
+        (c.comp ? calls_rev : calls_for).push_back(g);
+    }
+    GACT_Batch(calls_for, (int)calls_for.size(), false, 0, &s, match_score, mismatch_score, gap_open, gap_extend, fout);
+    GACT_Batch(calls_rev, (int)calls_rev.size(), true, (int)calls_for.size(), &s, match_score, mismatch_score,
+               gap_open, gap_extend, fout);
+    fout.close();
+}
+
+static void print_queue(const char *tag, std::queue<int> q)
+{
+    printf("%s", tag);
+    while (!q.empty()) { printf(" %d", q.front()); q.pop(); }
+    printf("\n");
+}
+
+// FILE lines:  T ref query match mismatch open ext reverse first early     -> AlignWithBT + Align_Batch_GPU
+//              G ref query ref_pos query_pos tile overlap thr match mismatch open ext comp -> GACT
+static int selftest(const char *path)
+{
+    std::ifstream in(path);
+    std::string kind;
+    std::vector<GPU_storage> s;
+    bool inited = false;
+    int n = 0;
+    while (in >> kind) {
+        if (kind == "T") {
+            std::string r, q; int m, x, o, e, rev, first, early;
+            in >> r >> q >> m >> x >> o >> e >> rev >> first >> early;
+            print_queue("AlignWithBT", AlignWithBT((char *)r.c_str(), (long long)r.size(), (char *)q.c_str(),
+                                                   (long long)q.size(), m, x, o, e, (int)q.size(), (int)r.size(),
+                                                   rev != 0, first != 0, early));
+            if (m == 1 && x == -1 && o == -1 && e == -1 && early == tile_size - tile_overlap &&
+                (int)r.size() <= tile_size && (int)q.size() <= tile_size) {
+                if (!inited) {
+                    NUM_BLOCKS = 1; THREADS_PER_BLOCK = 4; BATCH_SIZE = 4;
+                    GPU_init(tile_size, tile_overlap, gap_open, gap_extend, match_score, mismatch_score,
+                             tile_size - tile_overlap, &s, 1);
+                    inited = true;
+                }
+                // slot 1 of a 4-slot batch, the others idle (ref_len -1, gact.cpp:303-305)
+                std::vector<std::string> rs(4), qs(4);
+                std::vector<int> rl(4, -1), ql(4, 0);
+                std::vector<char> rv(4, 0), fs(4, 0);
+                rs[1] = r; qs[1] = q; rl[1] = (int)r.size(); ql[1] = (int)q.size();
+                rv[1] = rev ? 0 : 1;      // Align_Batch_GPU's sense is the opposite of AlignWithBT's
+                fs[1] = (char)first;
+                int *out = Align_Batch_GPU(rs, qs, rl, ql, nullptr, gap_open, gap_extend, rl, ql, rv, fs,
+                                           tile_size - tile_overlap, tile_size, &s[0], NUM_BLOCKS, THREADS_PER_BLOCK);
+                const int *o1 = out + 2 * tile_size;
+                printf("Align_Batch_GPU %d %d %d %d %d :", o1[0], o1[1], o1[2], o1[3], o1[4]);
+                for (int k = 5; o1[k] != -1; k++) printf(" %d", o1[k]);
+                printf("\n");
+                free(out);
+            }
+        } else if (kind == "G") {
+            std::string r, q; int rp, qp, t, ov, thr, m, x, o, e, comp;
+            in >> r >> q >> rp >> qp >> t >> ov >> thr >> m >> x >> o >> e >> comp;
+            reference_descrips.assign(1, std::vector<std::string>(1, "refname"));
+            reads_descrips.assign(2, std::vector<std::string>(1, "queryname"));
+            same_file = false;
+            const char *tmp = "selftest_gact.out";
+            { std::ofstream fout(tmp);
+              GACT((char *)r.c_str(), (char *)q.c_str(), (int)r.size(), (int)q.size(), t, ov, rp, qp, thr, 0, 1,
+                   comp != 0, m, x, o, e, fout); }
+            std::ifstream back(tmp); std::stringstream ss; ss << back.rdbuf();
+            printf("GACT %s", ss.str().empty() ? "\n" : ss.str().c_str());
+            remove(tmp);
+        }
+        n++;
+    }
+    if (inited) GPU_close(&s, 1);
+    return n > 0 ? 0 : 1;
+}
+
+int main(int argc, char *argv[])
+{
+    if (argc >= 3 && strcmp(argv[1], "--selftest") == 0) return selftest(argv[2]);
+    if (argc < 4) {
+        fprintf(stderr, "Usage: darwin_hip <REFERENCE>.fasta <READS>.fasta CPU_THREADS --candidates FILE "
+                        "[--params params.cfg]\n");
+        return 1;
+    }
+    std::string cand_path, cfg_path = "params.cfg";
+    for (int a = 4; a + 1 < argc; a += 2) {
+        if (!strcmp(argv[a], "--candidates")) cand_path = argv[a + 1];
+        else if (!strcmp(argv[a], "--params")) cfg_path = argv[a + 1];
+    }
+    std::map<std::string, double> cfg = parse_cfg(cfg_path);
+    auto get = [&](const char *k, int dflt) { return cfg.count(k) ? (int)cfg[k] : dflt; };
+    match_score = get("GACT_scoring/match", 1); mismatch_score = get("GACT_scoring/mismatch", -1);
+    gap_open = get("GACT_scoring/gap_open", -1); gap_extend = get("GACT_scoring/gap_extend", -1);
+    first_tile_score_threshold = get("GACT_first_tile/first_tile_score_threshold", 35);
+    tile_size = get("GACT_extend/tile_size", 320); tile_overlap = get("GACT_extend/tile_overlap", 120);
+    num_threads = std::stoi(argv[3]);
+    const std::string ref_path(argv[1]), reads_path(argv[2]);
+    same_file = (ref_path == reads_path);                         // darwin.cpp:500-502
+    printf("same_file: %d\n", same_file);
+    printf("Scores: match = %d, mismatch = %d, gap_open = %d, gap_extend = %d\n", match_score, mismatch_score,
+           gap_open, gap_extend);
+
+    std::vector<long long int> dummy;
+    parse_fasta(ref_path, reference_descrips, reference_seqs, reference_lengths);
+    parse_fasta(reads_path, reads_descrips, reads_seqs, reads_lengths);
+    for (const std::string &r : reads_seqs) rev_reads_seqs.push_back(rev_comp(r));
+    std::cout << "Number of reads: " << reads_seqs.size() << std::endl;
+
+    std::vector<Cand> cands;
+    {
+        std::ifstream in(cand_path, std::ios::binary);
+        if (!in) { fprintf(stderr, "cannot open candidates file '%s'\n", cand_path.c_str()); return 1; }
+        Cand c;
+        while (in.read((char *)&c, sizeof c)) cands.push_back(c);
+    }
+    printf("num_candidates: %zu\n", cands.size());
+
+    std::vector<GPU_storage> s;
+    GPU_init(tile_size, tile_overlap, gap_open, gap_extend, match_score, mismatch_score, tile_size - tile_overlap,
+             &s, num_threads);
+    std::vector<std::thread> threads;
+    const size_t per = (cands.size() + num_threads - 1) / (num_threads > 0 ? num_threads : 1);
+    for (int i = 0; i < num_threads; i++) {
+        const size_t lo = std::min(cands.size(), i * per), hi = std::min(cands.size(), lo + per);
+        threads.push_back(std::thread(feeder, i, &cands, lo, hi, s[i]));
+    }
+    for (auto &t : threads) t.join();
+    GPU_close(&s, num_threads);
+    return 0;
+}

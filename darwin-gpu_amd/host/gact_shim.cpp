@@ -1,0 +1,255 @@
+// gact_shim.cpp -- the reference's C++ entry points implemented on the C-ABI
+// (include/gact_hip.h).  Error behaviour follows the reference: a failed
+// device call prints and exit(-1)s (cudaSafeCall, cuda_header.h:309-319).
+#include "gact.h"
+#include "align.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "gact_hip.h"
+
+// globals of the driver that gact.cpp reads (gact.cpp:39-46)
+extern bool same_file;
+extern std::vector<std::string> reference_seqs;
+extern std::vector<long long int> reference_lengths;
+extern std::vector<std::string> reads_seqs;
+extern std::vector<std::string> rev_reads_seqs;
+extern std::vector<long long int> reads_lengths;
+extern std::vector<std::vector<std::string> > reference_descrips;
+extern std::vector<std::vector<std::string> > reads_descrips;
+
+namespace {
+
+void die(const char *what)
+{
+    printf("\n%s failed: %s\n\n", what, gact_hip_last_error());
+    exit(-1);
+}
+#define SAFE(call) do { if ((call) != 0) die(#call); } while (0)
+
+struct Main {
+    gact_hip_engine *engine = nullptr;
+    gact_hip_params params;
+    std::once_flag uploaded;
+    int scores[4];
+} g_main;
+
+void upload_set(gact_hip_engine *e, int which, const std::vector<std::string> &seqs)
+{
+    std::vector<int64_t> offs(seqs.size() + 1, 0);
+    for (size_t k = 0; k < seqs.size(); k++) offs[k + 1] = offs[k] + (int64_t)seqs[k].size();
+    std::vector<uint8_t> cat((size_t)offs.back());
+    for (size_t k = 0; k < seqs.size(); k++) memcpy(cat.data() + offs[k], seqs[k].data(), seqs[k].size());
+    SAFE(gact_hip_upload_seqs(e, which, cat.data(), offs.data(), (int32_t)seqs.size()));
+}
+
+// the driver's read sets become resident the first time a batch needs them
+// (after darwin.cpp:314-398 has recoded them; ASCII and 0..3 are both accepted)
+void ensure_reads_resident()
+{
+    std::call_once(g_main.uploaded, [] {
+        upload_set(g_main.engine, GACT_SET_REF, reference_seqs);
+        upload_set(g_main.engine, GACT_SET_QUERY, reads_seqs);
+        upload_set(g_main.engine, GACT_SET_QUERY_RC, rev_reads_seqs);
+    });
+}
+
+void print_overlap(std::ofstream &fout, const gact_overlap &o)
+{
+    char line[1024];
+    int n = gact_hip_format_overlap(&o, reference_descrips[o.ref_id][0].c_str(),
+                                    reads_descrips[o.query_id][0].c_str(), line, sizeof line);
+    if (n < 0) die("gact_hip_format_overlap");
+    fout.write(line, n);
+    fout.flush();
+}
+
+// small engines for the align.h / GACT() surface, keyed by what the kernels bake in
+typedef std::tuple<int, int, int, int, int, int, int> Key;   // tile, overlap, match, mismatch, open, ext, thr
+std::mutex g_side_mu;
+std::map<Key, gact_hip_engine *> g_side;
+
+gact_hip_engine *side_engine(int tile, int overlap, int match, int mismatch, int open, int ext, int thr)
+{
+    const Key k(tile, overlap, match, mismatch, open, ext, thr);
+    auto it = g_side.find(k);
+    if (it != g_side.end()) return it->second;
+    gact_hip_params p;
+    memset(&p, 0, sizeof p);
+    p.tile_size = tile; p.tile_overlap = overlap;
+    p.match = match; p.mismatch = mismatch; p.gap_open = open; p.gap_extend = ext;
+    p.first_tile_score_threshold = thr; p.device_id = 0; p.n_slots = 1;
+    gact_hip_engine *e = nullptr;
+    SAFE(gact_hip_create(&p, &e));
+    g_side[k] = e;
+    return e;
+}
+
+}  // namespace
+
+void GPU_init(int tile_size_, int tile_overlap_, int gap_open, int gap_extend, int match, int mismatch,
+              int early_terminate, std::vector<GPU_storage> *s, int num_threads)
+{
+    (void)early_terminate;   // always tile_size - tile_overlap (darwin.cpp:611)
+    gact_hip_params p;
+    memset(&p, 0, sizeof p);
+    p.tile_size = tile_size_; p.tile_overlap = tile_overlap_;
+    p.match = match; p.mismatch = mismatch; p.gap_open = gap_open; p.gap_extend = gap_extend;
+    p.first_tile_score_threshold = first_tile_score_threshold;
+    p.device_id = 0;                       // cuda_host.cu:195
+    p.n_slots = num_threads;
+    SAFE(gact_hip_create(&p, &g_main.engine));
+    g_main.params = p;
+    for (int i = 0; i < num_threads; ++i) {
+        GPU_storage st;
+        st.engine = g_main.engine; st.slot = i; st.reserved = 0;
+        s->push_back(st);
+    }
+    gact_hip_device_info info;
+    SAFE(gact_hip_get_device_info(g_main.engine, &info));
+    printf("%s: %d CUs, %lld MB HBM, %d feeder slots\n", info.arch, info.compute_units,
+           (long long)(info.hbm_bytes >> 20), num_threads);
+}
+
+void GPU_close(std::vector<GPU_storage> *s, int num_threads)
+{
+    (void)num_threads;
+    if (g_main.engine) gact_hip_destroy(g_main.engine);
+    g_main.engine = nullptr;
+    s->clear();
+}
+
+void GACT_Batch(std::vector<GACT_call> calls, int num_calls, bool complement, int offset, GPU_storage *s,
+                int match_score, int mismatch_score, int gap_open, int gap_extend, std::ofstream &fout)
+{
+    (void)offset; (void)match_score; (void)mismatch_score; (void)gap_open; (void)gap_extend;
+    printf("GACT_Batch, num_calls: %d, complement: %d\n", num_calls, complement);   // gact.cpp:249
+    if (num_calls <= 0) return;
+    ensure_reads_resident();
+    gact_hip_engine *e = (gact_hip_engine *)s->engine;
+    std::vector<gact_candidate> cands(num_calls);
+    for (int k = 0; k < num_calls; k++) {
+        cands[k].ref_id = calls[k].ref_id; cands[k].query_id = calls[k].query_id;
+        cands[k].ref_pos = calls[k].ref_pos; cands[k].query_pos = calls[k].query_pos;
+    }
+    std::vector<gact_overlap> out(num_calls);
+    SAFE(gact_hip_extend_candidates(e, s->slot, num_calls, cands.data(), complement ? 1 : 0, same_file ? 1 : 0,
+                                    out.data()));
+    for (int k = 0; k < num_calls; k++)
+        if (out[k].emitted) print_overlap(fout, out[k]);
+}
+
+int *Align_Batch_GPU(std::vector<std::string> ref_seqs, std::vector<std::string> query_seqs,
+                     std::vector<int> ref_lens, std::vector<int> query_lens,
+                     int *sub_mat, int gap_open, int gap_extend,
+                     std::vector<int> ref_poss, std::vector<int> query_poss,
+                     std::vector<char> reverses, std::vector<char> firsts,
+                     int early_terminate, int tile_size_, GPU_storage *s,
+                     int num_blocks, int threads_per_block)
+{
+    (void)sub_mat; (void)gap_open; (void)gap_extend; (void)ref_poss; (void)query_poss; (void)early_terminate;
+    const int batch = num_blocks * threads_per_block;
+    gact_hip_engine *e = (gact_hip_engine *)s->engine;
+    const int stride = tile_size_ > 0 ? tile_size_ : 1;
+    std::vector<uint8_t> rb((size_t)batch * stride), qb((size_t)batch * stride), rev(batch), fst(batch);
+    std::vector<int32_t> rl(batch), ql(batch);
+    for (int t = 0; t < batch; t++) {
+        rl[t] = ref_lens[t];
+        ql[t] = (ref_lens[t] == -1) ? 0 : query_lens[t];
+        if (ref_lens[t] == -1) { rev[t] = 0; fst[t] = 0; continue; }
+        memcpy(rb.data() + (size_t)t * stride, ref_seqs[t].data(), (size_t)rl[t]);
+        memcpy(qb.data() + (size_t)t * stride, query_seqs[t].data(), (size_t)ql[t]);
+        // reverses[t]==1 (towards 0) keeps the bytes as they are, ==0 byte-reverses them
+        // (cuda_host.cu:92-142): the opposite of AlignWithBT's `reverse`
+        rev[t] = reverses[t] == 1 ? 0 : 1;
+        fst[t] = firsts[t] == 1 ? 1 : 0;
+    }
+    std::vector<gact_tile_result> res(batch);
+    const int sstride = 2 * tile_size_;
+    std::vector<uint8_t> st((size_t)batch * sstride);
+    SAFE(gact_hip_align_tiles_inline(e, s->slot, batch, rb.data(), qb.data(), stride, rl.data(), ql.data(),
+                                     rev.data(), fst.data(), res.data(), st.data(), sstride));
+    int *out = (int *)malloc((size_t)batch * sizeof(int) * 2 * tile_size_);
+    for (int t = 0; t < batch; t++) {
+        int *o = out + (size_t)t * 2 * tile_size_;
+        if (ref_lens[t] == -1) { o[0] = 0; o[1] = o[2] = o[3] = o[4] = 0; o[5] = -1; continue; }
+        o[0] = res[t].score; o[1] = res[t].ref_steps; o[2] = res[t].query_steps;
+        o[3] = res[t].max_i; o[4] = res[t].max_j;
+        const int n = res[t].n_states < sstride - 6 ? res[t].n_states : sstride - 6;
+        for (int k = 0; k < n; k++) o[5 + k] = st[(size_t)t * sstride + k];
+        o[5 + n] = -1;
+    }
+    return out;
+}
+
+std::queue<int> AlignWithBT(char *ref_seq, long long int ref_len, char *query_seq, long long int query_len,
+                            int match_score, int mismatch_score, int gap_open, int gap_extend,
+                            int query_pos, int ref_pos, bool reverse, bool first, int early_terminate)
+{
+    std::queue<int> q;
+    if (ref_len > GACT_HIP_MAX_TILE || query_len > GACT_HIP_MAX_TILE || ref_len < 0 || query_len < 0 ||
+        ref_pos != ref_len || query_pos != query_len) {
+        printf("\nAlignWithBT: tile %lld x %lld (pos %d,%d) outside what the HIP engine supports\n\n", ref_len,
+               query_len, ref_pos, query_pos);
+        exit(-1);
+    }
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    const int tile = GACT_HIP_MAX_TILE;
+    int early = early_terminate < 1 ? 1 : (early_terminate > tile ? tile : early_terminate);
+    gact_hip_engine *e = side_engine(tile, tile - early, match_score, mismatch_score, gap_open, gap_extend, 1);
+    const int32_t rl = (int32_t)ref_len, ql = (int32_t)query_len;
+    const uint8_t rv = reverse ? 1 : 0, fs = first ? 1 : 0;
+    gact_tile_result res;
+    std::vector<uint8_t> st(2 * tile);
+    std::vector<uint8_t> rbuf(tile, 0), qbuf(tile, 0);
+    memcpy(rbuf.data(), ref_seq, (size_t)rl);
+    memcpy(qbuf.data(), query_seq, (size_t)ql);
+    SAFE(gact_hip_align_tiles_inline(e, 0, 1, rbuf.data(), qbuf.data(), tile, &rl, &ql, &rv, &fs, &res, st.data(),
+                                     2 * tile));
+    q.push(res.score);
+    if (first) { q.push(res.max_i); q.push(res.max_j); }
+    if (early_terminate >= 1)
+        for (int k = 0; k < res.n_states; k++) q.push(st[k]);
+    return q;
+}
+
+std::vector<std::queue<int> > Align_Batch(std::vector<std::string> ref_seqs, std::vector<std::string> query_seqs,
+                                          std::vector<int> ref_lens, std::vector<int> query_lens,
+                                          int match_score, int mismatch_score, int gap_open, int gap_extend,
+                                          std::vector<int> ref_poss_b, std::vector<int> query_poss_b,
+                                          std::vector<char> reverses, std::vector<char> firsts, int early_terminate)
+{
+    std::vector<std::queue<int> > result;
+    for (size_t j = 0; j < ref_seqs.size(); ++j) {
+        if (ref_lens[j] == -1) { result.push_back(std::queue<int>()); continue; }    // align.cpp:40-44
+        result.push_back(AlignWithBT((char *)ref_seqs[j].c_str(), ref_lens[j], (char *)query_seqs[j].c_str(),
+                                     query_lens[j], match_score, mismatch_score, gap_open, gap_extend,
+                                     query_poss_b[j], ref_poss_b[j], reverses[j] == 1, firsts[j] == 1,
+                                     early_terminate));
+    }
+    return result;
+}
+
+void GACT(char *ref_str, char *query_str, int ref_length, int query_length, int tile_size_, int tile_overlap_,
+          int ref_pos, int query_pos, int first_tile_score_threshold_, int ref_id, int query_id, bool complement,
+          int match_score, int mismatch_score, int gap_open, int gap_extend, std::ofstream &fout)
+{
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    gact_hip_engine *e = side_engine(tile_size_, tile_overlap_, match_score, mismatch_score, gap_open, gap_extend,
+                                     first_tile_score_threshold_);
+    // the two reads of this one call become a two-sequence resident set
+    const int64_t roffs[2] = {0, ref_length}, qoffs[2] = {0, query_length};
+    SAFE(gact_hip_upload_seqs(e, GACT_SET_REF, (const uint8_t *)ref_str, roffs, 1));
+    SAFE(gact_hip_upload_seqs(e, complement ? GACT_SET_QUERY_RC : GACT_SET_QUERY, (const uint8_t *)query_str, qoffs, 1));
+    gact_candidate c;
+    c.ref_id = 0; c.query_id = 0; c.ref_pos = ref_pos; c.query_pos = query_pos;
+    gact_overlap o;
+    SAFE(gact_hip_extend_candidates(e, 0, 1, &c, complement ? 1 : 0, 0, &o));
+    o.ref_id = ref_id; o.query_id = query_id;
+    if (!(same_file && ref_id == query_id) && o.score > 0) print_overlap(fout, o);     // gact.cpp:213
+}

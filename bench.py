@@ -70,32 +70,15 @@ def main():
 
     import numpy as np
     from gact_amd import engine, workload
+    from gact_amd import dist as gdist
 
     # ---- workload: one genome block per rank, read sets replicated everywhere
     t_gen = time.time()
     blk = workload.make_block(args.workload, block=rank)
-    blocks_reads = [blk.rs.reads]
-    blocks_cf, blocks_cr = [blk.cf], [blk.cr]
-    if world > 1:
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (blk.rs.reads, blk.cf, blk.cr))
-        blocks_reads = [g[0] for g in gathered]
-        blocks_cf = [g[1] for g in gathered]
-        blocks_cr = [g[2] for g in gathered]
-    reads, cf_all, cr_all = [], [], []
-    base = 0
-    for rd, cf, cr in zip(blocks_reads, blocks_cf, blocks_cr):
-        for c, dst in ((cf, cf_all), (cr, cr_all)):
-            c = c.copy()
-            c["ref_id"] += base
-            c["query_id"] += base
-            dst.append(c)
-        reads.extend(rd)
-        base += len(rd)
-    cf_all = np.concatenate(cf_all)
-    cr_all = np.concatenate(cr_all)
-    my_cf = workload.shard(cf_all, rank, world)
-    my_cr = workload.shard(cr_all, rank, world)
+    blocks = gdist.exchange_blocks(dist, (blk.rs.reads, blk.cf, blk.cr), world)
+    reads, cf_all, cr_all = gdist.merge_blocks(blocks)
+    my_cf = gdist.deal(cf_all, rank, world)
+    my_cr = gdist.deal(cr_all, rank, world)
     from gact_amd import synth
     offs = np.zeros(len(reads) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([len(r) for r in reads])
@@ -130,17 +113,7 @@ def main():
         gathered = None
         if use_dist:
             # the one collective of the path: gather of fixed-size overlap records
-            mine = np.concatenate([rf, rr]).view(np.uint8).reshape(-1, engine.OVERLAP_DTYPE.itemsize)
-            counts = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-            dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device="cuda"))
-            mx = int(max(int(c.item()) for c in counts))
-            buf = torch.zeros((mx, mine.shape[1]), dtype=torch.uint8, device="cuda")
-            buf[:mine.shape[0]] = torch.from_numpy(mine).cuda()
-            outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-            dist.gather(buf, outs, dst=0)
-            if rank == 0:
-                gathered = [o[:int(c.item())].cpu().numpy().view(engine.OVERLAP_DTYPE).reshape(-1)
-                            for o, c in zip(outs, counts)]
+            gathered = gdist.gather_records(torch, dist, rec, rank, world, "cuda")
         return rf, rr, gathered
 
     for _ in range(args.warmup):

@@ -52,10 +52,11 @@ struct KParams {
 
 template <int C> struct Geometry {
     static constexpr int kTileMax = C * kGroup;
-    static constexpr int kRefLds = kGroup + kTileMax + kGroup;   // front pad + bases + tail pad
+    static constexpr int kMaxSteps = kTileMax + kGroup;
+    // front pad (skew + the largest start delay) + bases + tail pad
+    static constexpr int kRefLds = kGroup + kMaxSteps + kTileMax + kGroup;
     static constexpr int kQueryLds = kTileMax;
     static constexpr int kGroupLds = kRefLds + kQueryLds;
-    static constexpr int kMaxSteps = kTileMax + kGroup;
     static constexpr int kMaxFlush = (kMaxSteps + 7) / 8 + 1;
     static constexpr int kWsWords = kMaxFlush * C * kGroup;
 };
@@ -114,6 +115,7 @@ __device__ __forceinline__ uint32_t fetch_base(const SeqSetDev &s, int64_t pos, 
 struct GroupTile {
     int R, Q;          // DP extent (0 => idle)
     int first;         // arg-max wanted (align.cpp:190)
+    int shift;         // steps this tile starts late (virtual rows in front), see align_starts()
 };
 
 struct PassOut {
@@ -121,6 +123,25 @@ struct PassOut {
     int best, bi, bj;  // arg-max, group-reduced        (align.cpp:173-177)
     int tB;            // first step whose pointers were stored
 };
+
+// The four tiles of a wave run in lock step: the pass ends at the largest last
+// step T* and pointer work starts at the smallest first-pointer step.  A short
+// tile would drag that start forward for everybody, so it is started late
+// instead (rows in front of row 1 are virtual and free): the latest common
+// start is tB* = min_g(tB_g + T* - Tend_g), and tile g is delayed by
+// max(0, tB* - tB_g), which never pushes it past T*.
+struct WavePlan { int T_end, tB; };
+__device__ __forceinline__ WavePlan align_starts(int Tend_g, int tB_g, bool active, int &shift)
+{
+    WavePlan wp;
+    wp.T_end = wave_max4(active ? Tend_g : 0);
+    const int reach = active ? tB_g + (wp.T_end - Tend_g) : 0x7fffffff;
+    int tB = wave_min4(reach);
+    if (tB == 0x7fffffff) tB = 1;
+    wp.tB = tB;
+    shift = active ? imax(0, tB - tB_g) : 0;
+    return wp;
+}
 
 // ---------------------------------------------------------------------------
 // The DP pass of one wave: four tiles, one per 16-lane group.
@@ -161,7 +182,7 @@ __device__ __forceinline__ void dp_pass(const KParams &kp, const int gl,
     auto step = [&](const int t, auto ptr_tag) {
         constexpr bool PTR = decltype(ptr_tag)::value;
         const uint32_t rb_next = ref_lds[t + 1];
-        const int row = t - gl;
+        const int row = t - gl - gt.shift;
 
         const int Ml0 = dpp_row_shr1(Mo_last, open);      // M[i][0] + open, M[i][0] = 0
         const int Dl0 = dpp_row_shr1(D_last, kNegInf);    // D[i][0] = -INF
@@ -270,6 +291,7 @@ __device__ __forceinline__ void dp_pass(const KParams &kp, const int gl,
 // ---------------------------------------------------------------------------
 // Traceback (align.cpp:185-230), run by one lane per group.
 
+// tB here is the wave's first stored step minus the tile's start delay
 template <int C>
 __device__ __forceinline__ uint32_t load_ptr(const uint32_t *ws, int i, int j, int tB)
 {
@@ -317,7 +339,7 @@ template <int C>
 __device__ __forceinline__ void load_tile(const SeqSetDev &rs, const SeqSetDev &qs, bool raw,
                                           int64_t rp0, int64_t qp0, int R, int Q, bool reverse,
                                           int gl, uint8_t *ref_lds_g, uint8_t *q_lds_g,
-                                          uint32_t (&qb)[C])
+                                          uint32_t (&qb)[C], int shift)
 {
     uint32_t rbv[C];
 #pragma unroll
@@ -329,13 +351,17 @@ __device__ __forceinline__ void load_tile(const SeqSetDev &rs, const SeqSetDev &
         rbv[c] = rv;
         qb[c] = qv;
     }
-    ref_lds_g[gl] = (uint8_t)kRefPad;                                        // front pad
-    ref_lds_g[kGroup + Geometry<C>::kTileMax + gl] = (uint8_t)kRefPad;       // tail pad
+    // row r (1-based) of this tile lives at ref_lds_g[kGroup + shift + r - 1]; everything in front
+    // (skew + start delay) and behind reads as the pad base
+    for (int k = gl; k < kGroup + shift; k += kGroup) ref_lds_g[k] = (uint8_t)kRefPad;
+    uint8_t *rrow = ref_lds_g + kGroup + shift;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        ref_lds_g[kGroup + gl * C + c] = (uint8_t)rbv[c];
+        rrow[gl * C + c] = (uint8_t)rbv[c];
         q_lds_g[gl * C + c] = (uint8_t)qb[c];
     }
+    for (int k = Geometry<C>::kTileMax + gl; k < Geometry<C>::kRefLds - kGroup - shift; k += kGroup)
+        rrow[k] = (uint8_t)kRefPad;
 }
 
 }  // namespace gact

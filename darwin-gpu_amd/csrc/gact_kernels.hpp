@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void align_tiles_kernel(
 
     for (int base = (w.slot - w.g); base < n; base += w.n_slots) {
         const int ti = base + w.g;
-        GroupTile gt{0, 0, 0};
+        GroupTile gt{0, 0, 0, 0};
         bool reverse = false, raw = false;
         int64_t rp0 = 0, qp0 = 0;
         const SeqSetDev *qs = &qfwd;
@@ -87,19 +87,18 @@ __global__ __launch_bounds__(kBlockThreads, 3) void align_tiles_kernel(
                 raw = refs.use_raw | qs->use_raw;
             }
         }
+        const bool active = gt.R > 0 && gt.Q > 0;
+        const WavePlan wp = align_starts(last_step<C>(gt.R, gt.Q),
+                                         first_pointer_step<C>(gt.R, gt.Q, kp.early, gt.first), active, gt.shift);
         uint32_t qb[C];
-        load_tile<C>(refs, *qs, raw, rp0, qp0, gt.R, gt.Q, reverse, w.gl, ref_lds_g, q_lds_g, qb);
+        load_tile<C>(refs, *qs, raw, rp0, qp0, gt.R, gt.Q, reverse, w.gl, ref_lds_g, q_lds_g, qb, gt.shift);
         wave_sync();
-
-        const int T_end = wave_max4(last_step<C>(gt.R, gt.Q));
-        const int tBg = (gt.R > 0 && gt.Q > 0) ? first_pointer_step<C>(gt.R, gt.Q, kp.early, gt.first) : 0x7fffffff;
-        int tB = wave_min4(tBg);
-        if (tB == 0x7fffffff) tB = 1;
         const bool any_first = __any(gt.first != 0);
 
         PassOut po;
-        if (any_first) dp_pass<C, true>(kp, w.gl, ref_lds_lane, qb, gt, T_end, tB, ws, po);
-        else           dp_pass<C, false>(kp, w.gl, ref_lds_lane, qb, gt, T_end, tB, ws, po);
+        if (any_first) dp_pass<C, true>(kp, w.gl, ref_lds_lane, qb, gt, wp.T_end, wp.tB, ws, po);
+        else           dp_pass<C, false>(kp, w.gl, ref_lds_lane, qb, gt, wp.T_end, wp.tB, ws, po);
+        po.tB -= gt.shift;      // the traceback indexes steps in the tile's own (undelayed) time
 
         // the pointer stores of all 16 lanes must have reached L2 before lane 0
         // reads them back (the loads bypass L1, load_ptr); same wave, same XCD,
@@ -182,7 +181,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
 
     for (;;) {
         // ---- pick the next tile of this group, finishing / fetching candidates on the way
-        GroupTile gt{0, 0, 0};
+        GroupTile gt{0, 0, 0, 0};
         bool reverse = false;
         int64_t rp0 = 0, qp0 = 0;
         bool have_tile = false;
@@ -263,21 +262,21 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
             if (__all(exhausted && s.phase == 2)) break;
             continue;
         }
-        if (!have_tile) { gt.R = 0; gt.Q = 0; gt.first = 0; }
+        if (!have_tile) { gt.R = 0; gt.Q = 0; gt.first = 0; gt.shift = 0; }
 
+        const bool active = gt.R > 0 && gt.Q > 0;
+        const WavePlan wp = align_starts(last_step<C>(gt.R, gt.Q),
+                                         first_pointer_step<C>(gt.R, gt.Q, kp.early, gt.first), active, gt.shift);
         uint32_t qb[C];
-        load_tile<C>(refs, s.comp ? qrc : qfwd, raw, rp0, qp0, gt.R, gt.Q, reverse, w.gl, ref_lds_g, q_lds_g, qb);
+        load_tile<C>(refs, s.comp ? qrc : qfwd, raw, rp0, qp0, gt.R, gt.Q, reverse, w.gl, ref_lds_g, q_lds_g, qb,
+                     gt.shift);
         wave_sync();
-
-        const int T_end = wave_max4(last_step<C>(gt.R, gt.Q));
-        const int tBg = (gt.R > 0 && gt.Q > 0) ? first_pointer_step<C>(gt.R, gt.Q, kp.early, gt.first) : 0x7fffffff;
-        int tB = wave_min4(tBg);
-        if (tB == 0x7fffffff) tB = 1;
         const bool any_first = __any(gt.first != 0);
 
         PassOut po;
-        if (any_first) dp_pass<C, true>(kp, w.gl, ref_lds_lane, qb, gt, T_end, tB, ws, po);
-        else           dp_pass<C, false>(kp, w.gl, ref_lds_lane, qb, gt, T_end, tB, ws, po);
+        if (any_first) dp_pass<C, true>(kp, w.gl, ref_lds_lane, qb, gt, wp.T_end, wp.tB, ws, po);
+        else           dp_pass<C, false>(kp, w.gl, ref_lds_lane, qb, gt, wp.T_end, wp.tB, ws, po);
+        po.tB -= gt.shift;      // the traceback indexes steps in the tile's own (undelayed) time
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see align_tiles_kernel
 
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
                         const bool gap = (state != GACT_STATE_M);
                         int sub = 0;
                         if (!gap) {
-                            const uint32_t rbv = ref_lds_g[kGroup + ci - 1];
+                            const uint32_t rbv = ref_lds_g[kGroup + gt.shift + ci - 1];
                             const uint32_t qbv = q_lds_g[cj - 1];
                             sub = (rbv == qbv) ? kp.match : kp.mismatch;     // gact.cpp:207
                         }

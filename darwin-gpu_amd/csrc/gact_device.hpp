@@ -291,16 +291,56 @@ __device__ __forceinline__ void dp_pass(const KParams &kp, const int gl,
 // ---------------------------------------------------------------------------
 // Traceback (align.cpp:185-230), run by one lane per group.
 
+// Pointer words are read back in 16-byte patches: one uint4 of the workspace
+// holds 4 adjacent columns x 8 consecutive rows of one lane, and a fetch also
+// brings the quad to its left, so a diagonal walk needs a new (HBM-latency)
+// fetch only every ~6 steps instead of every step.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int C> struct PtrPatch {
+    u32x4 cur, left;     // quads q and q-1 of one (flush block, lane)
+    int key;             // uint4 index of `cur` in the workspace, -1 = nothing cached
+    int has_left;
+};
+
+// The words were written by other lanes of this wave during the pass and the
+// same addresses held the previous tile's pointers: read past the L1 (sc1).
+__device__ __forceinline__ void fetch_patch(const u32x4 *p, bool with_left, u32x4 &cur, u32x4 &left)
+{
+    if (with_left) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                     "global_load_dwordx4 %1, %3, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(cur), "=&v"(left) : "v"(p), "v"(p - kGroup) : "memory");
+    } else {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(cur) : "v"(p) : "memory");
+    }
+}
+
 // tB here is the wave's first stored step minus the tile's start delay
 template <int C>
-__device__ __forceinline__ uint32_t load_ptr(const uint32_t *ws, int i, int j, int tB)
+__device__ __forceinline__ uint32_t load_ptr(const uint32_t *ws, PtrPatch<C> &pc, int i, int j, int tB)
 {
     const int l = (j - 1) / C;
     const int c = (j - 1) - l * C;
     const int k = i + l - tB;
-    const uint32_t *p = ws + ((((k >> 3) * (C / 4) + (c >> 2)) * kGroup + l) << 2) + (c & 3);
-    // written by other lanes of this wave during the pass: read past the L1
-    const uint32_t w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int q = c >> 2;
+    const int key = ((k >> 3) * (C / 4) + q) * kGroup + l;
+    u32x4 v;
+    if (key == pc.key) {
+        v = pc.cur;
+    } else if (pc.has_left && key == pc.key - kGroup) {
+        v = pc.left;
+    } else {
+        fetch_patch(reinterpret_cast<const u32x4 *>(ws) + key, q > 0, pc.cur, pc.left);
+        pc.key = key;
+        pc.has_left = q > 0;
+        v = pc.cur;
+    }
+    const int wi = c & 3;
+    const uint32_t w = wi == 0 ? v.x : (wi == 1 ? v.y : (wi == 2 ? v.z : v.w));
     return (w >> (28 - 4 * (k & 7))) & 15u;
 }
 
@@ -313,8 +353,10 @@ __device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int 
     int is = 0, js = 0;
     int state = GACT_STATE_Z;
     uint32_t nib = 0;
+    PtrPatch<C> pc;
+    pc.key = -1; pc.has_left = 0;
     if (i >= 1 && j >= 1 && early > 0) {
-        nib = load_ptr<C>(ws, i, j, tB);
+        nib = load_ptr<C>(ws, pc, i, j, tB);
         state = nib & 3;
     }
     while (state != GACT_STATE_Z) {
@@ -325,7 +367,117 @@ __device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int 
         else { next = (nib & 4) ? GACT_STATE_M : GACT_STATE_D; j--; js++; }
         if (is >= early || js >= early) break;       // align.cpp:205
         if (i < 1 || j < 1) break;                   // border pointers are ZERO (align.cpp:101-107)
-        nib = load_ptr<C>(ws, i, j, tB);
+        nib = load_ptr<C>(ws, pc, i, j, tB);
+        state = (next < 0) ? (int)(nib & 3) : next;
+    }
+    ref_steps = is;
+    query_steps = js;
+}
+
+// ---------------------------------------------------------------------------
+// Region-cached traceback.  Several walkers (one lane each) run this loop in
+// lock step, so a per-step pointer load would cost every walker a full memory
+// round trip whenever ANY of them misses.  Instead every kTbSpan steps each
+// walker copies the whole region it can reach in the next kTbSpan steps
+// (rows i-8..i, columns j-8..j: 2 lanes x 2 flush blocks x 3 column quads =
+// 12 uint4) from the HBM workspace into its own LDS scratch -- all 12 loads in
+// flight at once, one latency per 8 steps -- and the steps in between read LDS.
+constexpr int kTbSpan = 8;
+constexpr int kTbScratchWords = 12 * 4;      // dwords of LDS per walker
+
+template <int C> struct TbRegion {
+    int l0;              // lane of the anchor column
+    int fbase[2];        // first cached flush block, for lane l0 and lane l0-1
+    int qbase0;          // first cached column quad of lane l0 (lane l0-1 always caches its last three)
+};
+
+template <int C>
+__device__ __forceinline__ void tb_refill(const uint32_t *ws, uint32_t *scratch, int i, int j, int tB,
+                                          TbRegion<C> &rg)
+{
+    constexpr int QN = C / 4;
+    const int l0 = (j - 1) / C;
+    const int c0 = (j - 1) - l0 * C;
+    rg.l0 = l0;
+    rg.qbase0 = imax(c0 - kTbSpan, 0) >> 2;
+    const u32x4 *base = reinterpret_cast<const u32x4 *>(ws);
+    const u32x4 *addr[12];
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+        const int k_anchor = i + (l0 - sl) - tB;
+        const int fb = imax((k_anchor >> 3) - 1, 0);
+        rg.fbase[sl] = fb;
+        const int lane = imax(l0 - sl, 0);
+        const int qb = sl ? QN - 3 : rg.qbase0;
+#pragma unroll
+        for (int lev = 0; lev < 2; lev++)
+#pragma unroll
+            for (int qq = 0; qq < 3; qq++)
+                addr[(sl * 2 + lev) * 3 + qq] = base + ((fb + lev) * QN + imin(qb + qq, QN - 1)) * kGroup + lane;
+    }
+    u32x4 r[12];
+#pragma unroll
+    for (int g = 0; g < 3; g++)
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                     "global_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc1"
+                     : "=&v"(r[4 * g]), "=&v"(r[4 * g + 1]), "=&v"(r[4 * g + 2]), "=&v"(r[4 * g + 3])
+                     : "v"(addr[4 * g]), "v"(addr[4 * g + 1]), "v"(addr[4 * g + 2]), "v"(addr[4 * g + 3])
+                     : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                   "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11])
+                 :: "memory");
+    u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
+#pragma unroll
+    for (int n = 0; n < 12; n++) dst[n] = r[n];
+}
+
+template <int C>
+__device__ __forceinline__ uint32_t tb_lookup(const uint32_t *scratch, int i, int j, int tB, const TbRegion<C> &rg)
+{
+    const int l = (j - 1) / C;
+    const int c = (j - 1) - l * C;
+    const int k = i + l - tB;
+    const int sl = rg.l0 - l;                                   // 0 or 1
+    const int lev = (k >> 3) - (sl ? rg.fbase[1] : rg.fbase[0]);
+    const int qq = (c >> 2) - (sl ? C / 4 - 3 : rg.qbase0);
+    const uint32_t w = scratch[(((sl * 2 + lev) * 3 + qq) << 2) + (c & 3)];
+    return (w >> (28 - 4 * (k & 7))) & 15u;
+}
+
+// Same walk as traceback() above (align.cpp:185-230); `scratch` is this lane's
+// kTbScratchWords dwords of LDS.  All lanes that enter take the same number of
+// steps between refills, so the refill branch is uniform among them.
+template <int C, class Emit>
+__device__ __forceinline__ void traceback_cached(const uint32_t *ws, uint32_t *scratch, int i, int j, int tB,
+                                                 int early, int &ref_steps, int &query_steps, Emit &&emit)
+{
+    int is = 0, js = 0;
+    int state = GACT_STATE_Z;
+    uint32_t nib = 0;
+    TbRegion<C> rg;
+    int since = 0;
+    if (i >= 1 && j >= 1 && early > 0) {
+        tb_refill<C>(ws, scratch, i, j, tB, rg);
+        nib = tb_lookup<C>(scratch, i, j, tB, rg);
+        state = nib & 3;
+    }
+    while (state != GACT_STATE_Z) {
+        emit(state, i, j);
+        const bool isM = state == GACT_STATE_M, isI = state == GACT_STATE_I, isD = state == GACT_STATE_D;
+        const int next = isM ? -1 : (isI ? ((nib & 8) ? GACT_STATE_M : GACT_STATE_I)
+                                         : ((nib & 4) ? GACT_STATE_M : GACT_STATE_D));
+        const int di = (isM | isI) ? 1 : 0, dj = (isM | isD) ? 1 : 0;
+        i -= di; j -= dj; is += di; js += dj;
+        if (is >= early || js >= early) break;       // align.cpp:205
+        if (i < 1 || j < 1) break;                   // border pointers are ZERO (align.cpp:101-107)
+        if (++since == kTbSpan) {
+            tb_refill<C>(ws, scratch, i, j, tB, rg);
+            since = 0;
+        }
+        nib = tb_lookup<C>(scratch, i, j, tB, rg);
         state = (next < 0) ? (int)(nib & 3) : next;
     }
     ref_steps = is;

@@ -19,6 +19,7 @@
 
 #include "gact_hip.h"
 #include "gact_kernels.hpp"
+#include "gact_p16.hpp"
 
 namespace {
 
@@ -88,14 +89,16 @@ template <class T> struct DevBuf {
 
 struct Slot {
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
+    bool timed = false, two_phase = false;
     DevBuf<gact_tile> tiles;
     DevBuf<gact_tile_result> results;
     DevBuf<uint8_t> states;
     DevBuf<gact_candidate> cands;
     DevBuf<gact_overlap> overlaps;
-    int *d_counter = nullptr;
+    int *d_counter = nullptr;            // 8 ints: pop_seed, live_count, pop_main, -, seed_cells(u64)
+    DevBuf<int> live;
+    DevBuf<gact::ChainState> chain_states;
     uint32_t *d_ws = nullptr;
     int *d_flags = nullptr;
     SeqSet inline_ref, inline_query;   // Align_Batch_GPU-style inline tiles
@@ -107,6 +110,8 @@ struct gact_hip_engine {
     gact_hip_params params;
     gact::KParams kp;
     int C = 20;                 // columns per lane
+    bool p16 = false;           // scoring fits the packed-int16 main kernel
+    gact::P16Consts kc;
     hipDeviceProp_t prop;
     int grid_blocks = 0;        // persistent grid
     int blocks_per_cu = 0;
@@ -196,6 +201,17 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
     return 0;
 }
 
+gact::ChainQueues queues(Slot &sl)
+{
+    gact::ChainQueues q;
+    q.pop_seed = sl.d_counter; q.live_count = sl.d_counter + 1; q.pop_main = sl.d_counter + 2;
+    q.seed_cells = reinterpret_cast<unsigned long long *>(sl.d_counter + 4);
+    q.live = sl.live.p; q.states = sl.chain_states.p;
+    return q;
+}
+
+// int32 kernel alone, or (scoring permitting) int32 seed launch for the first
+// tiles followed by the packed-int16 main launch for the rest of every chain
 template <int C>
 int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, int same_file)
 {
@@ -203,13 +219,23 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
     const bool need_f = first < rc_from, need_r = first + n > rc_from;
     const bool raw = rs.has_other || (need_f && qf.has_other) || (need_r && qr.has_other);
-    const int waves_needed = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
-    const int blocks_needed = (waves_needed + 3) / 4;
-    const int blocks = std::max(1, std::min(blocks_needed, e->grid_blocks));
-    hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream,
+    const int groups_needed = e->p16 ? (n + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave)
+                                     : (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
+    const int seed_waves = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
+    const int seed_blocks = std::max(1, std::min((seed_waves + 3) / 4, e->grid_blocks));
+    const int main_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->grid_blocks));
+    hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
                        e->kp, rs.dev(raw), qf.dev(raw), qr.dev(raw), sl.cands.p, first, n, rc_from, same_file,
-                       sl.overlaps.p, sl.d_counter, sl.d_ws);
+                       sl.overlaps.p, queues(sl), e->p16 ? 1 : 0, sl.d_ws);
     HIP_TRY(hipGetLastError());
+    sl.two_phase = e->p16;
+    if (e->p16) {
+        HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
+        hipLaunchKernelGGL((gact::extend_p16_kernel<C>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
+                           sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev(raw), qr.dev(raw), same_file,
+                           sl.overlaps.p, queues(sl), sl.d_ws);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -218,7 +244,9 @@ template <int C> int occupancy_blocks(int *out)
     int a = 0, b = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
-    *out = std::max(1, std::min(a, b));
+    int c = a;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::extend_p16_kernel<C>, gact::kBlockThreads, 0));
+    *out = std::max(1, std::min(std::min(a, b), c));
     return 0;
 }
 
@@ -311,18 +339,24 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->kp.open = p->gap_open; e->kp.ext = p->gap_extend;
     e->kp.thr = p->first_tile_score_threshold;
     e->kp.ws_words = (e->C == 20) ? gact::Geometry<20>::kWsWords : gact::Geometry<32>::kWsWords;
+    e->p16 = gact::p16_scoring_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
+             getenv("GACT_HIP_FORCE_INT32") == nullptr;
+    e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);
+    e->kc.open = gact::pk2(p->gap_open); e->kc.ext = gact::pk2(p->gap_extend);
+    e->kc.ninf = gact::pk2(gact::kNegInf16); e->kc.one = gact::pk2(1);
 
     rc = (e->C == 20) ? occupancy_blocks<20>(&e->blocks_per_cu) : occupancy_blocks<32>(&e->blocks_per_cu);
     if (rc) { delete e; return rc; }
     e->grid_blocks = e->blocks_per_cu * e->prop.multiProcessorCount;
     const size_t groups = (size_t)e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
-    e->ws_words_total = groups * (size_t)e->kp.ws_words;
+    e->ws_words_total = groups * gact::kSlots * (size_t)e->kp.ws_words;    // two tiles per group in the p16 kernel
 
     e->slots.resize(p->n_slots);
     for (auto &sl : e->slots) {
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
-            hipMalloc((void **)&sl.d_counter, sizeof(int)) != hipSuccess ||
+            hipEventCreate(&sl.ev_mid) != hipSuccess ||
+            hipMalloc((void **)&sl.d_counter, 8 * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&sl.d_flags, sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&sl.d_ws, e->ws_words_total * sizeof(uint32_t)) != hipSuccess) {
             gact_hip_destroy(e);
@@ -341,13 +375,14 @@ void gact_hip_destroy(gact_hip_engine *e)
     for (auto &sl : e->slots) {
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
         sl.tiles.release(); sl.results.release(); sl.states.release();
-        sl.cands.release(); sl.overlaps.release();
+        sl.cands.release(); sl.overlaps.release(); sl.live.release(); sl.chain_states.release();
         sl.inline_ref.release(); sl.inline_query.release();
         if (sl.d_counter) (void)hipFree(sl.d_counter);
         if (sl.d_flags) (void)hipFree(sl.d_flags);
         if (sl.d_ws) (void)hipFree(sl.d_ws);
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
         if (sl.ev1) (void)hipEventDestroy(sl.ev1);
+        if (sl.ev_mid) (void)hipEventDestroy(sl.ev_mid);
         if (sl.stream) (void)hipStreamDestroy(sl.stream);
     }
     for (auto &s : e->sets) s.release();
@@ -456,7 +491,8 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
         if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0 || c.query_pos > ql)
             return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
     }
-    if (sl.cands.reserve(n) || sl.overlaps.reserve(n)) return fail(GACT_HIP_ENOMEM, "device allocation failed");
+    if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve(n) || sl.chain_states.reserve(n))
+        return fail(GACT_HIP_ENOMEM, "device allocation failed");
     if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, cands, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
                                   sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
@@ -476,8 +512,9 @@ int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, i
     if (n > 0 && (e->sets[GACT_SET_REF].n == 0 || (need_f && e->sets[GACT_SET_QUERY].n == 0) ||
                   (need_r && e->sets[GACT_SET_QUERY_RC].n == 0)))
         return fail(GACT_HIP_EINVAL, "candidates_run: read sets not uploaded");
-    HIP_TRY(hipMemsetAsync(sl.d_counter, 0, sizeof(int), sl.stream));
+    HIP_TRY(hipMemsetAsync(sl.d_counter, 0, 8 * sizeof(int), sl.stream));
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
+    sl.two_phase = false;
     if (n > 0) {
         rc = (e->C == 20) ? launch_extend<20>(e, sl, first, n, rc_from, same_file)
                           : launch_extend<32>(e, sl, first, n, rc_from, same_file);
@@ -544,6 +581,30 @@ int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms)
     return 0;
 }
 
+int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if (!st) return fail(GACT_HIP_EINVAL, "stats is NULL");
+    Slot &sl = e->slots[slot];
+    if (!sl.timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
+    if ((rc = set_device(e))) return rc;
+    memset(st, 0, sizeof *st);
+    HIP_TRY(hipEventSynchronize(sl.ev1));
+    HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
+    st->main_ms = st->total_ms;
+    st->packed16 = sl.two_phase ? 1 : 0;
+    if (sl.two_phase) {
+        HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
+        HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));
+        int c[8];
+        HIP_TRY(hipMemcpy(c, sl.d_counter, sizeof c, hipMemcpyDeviceToHost));
+        st->handed_off = c[1];
+        memcpy(&st->seed_cells, &c[4], sizeof(int64_t));
+    }
+    return 0;
+}
+
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot)
 {
     if (check_slot(e, slot)) return nullptr;
@@ -585,6 +646,20 @@ int gact_hip_measure_valu_rate(gact_hip_engine *e, double *lane_ops_per_s)
     *lane_ops_per_s = ops / (best * 1e-3);
     return 0;
 }
+
+#ifdef GACT_STAMPS
+// diagnostic build: read and clear the per-phase clock totals of extend_p16_kernel
+int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
+{
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(gact::g_stamps), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_stamps), z, sizeof z));
+    return 0;
+}
+#endif
 
 int gact_hip_format_overlap(const gact_overlap *o, const char *ref_name, const char *query_name, char *buf,
                             int32_t cap)

@@ -10,6 +10,7 @@
 #include <type_traits>
 
 #include "gact_device.hpp"
+#include "gact_chain.hpp"
 
 namespace gact {
 
@@ -127,39 +128,20 @@ __global__ __launch_bounds__(kBlockThreads, 3) void align_tiles_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Persistent chain kernel.  Per-group state mirrors the locals of GACT()
-// (gact.cpp:57-79); every lane of the group carries an identical copy, only
-// the traceback runs on one lane and its results are broadcast.
-
-struct ChainState {
-    int cand;            // index into cands, -1 = none
-    int ref_id, query_id;
-    int ref_len, query_len;       // whole-read lengths
-    int64_t rbase, qbase;         // concat offsets of the two reads
-    int ref_pos, query_pos;
-    int rev_ref_pos, rev_query_pos;
-    int abpos, bbpos;
-    int i, j;                     // gact.cpp's i (query steps) / j (ref steps) of the last tile
-    int first_tile;               // gact.cpp:79
-    int first_tile_score;
-    int phase;                    // 0 left, 1 right, 2 done
-    int brk;                      // threshold `break` pending (gact.cpp:107-109,168-170)
-    // rescoring (gact.cpp:197-210) folded into the walk, see DESIGN.md 3.5
-    int score;
-    int pend_gap;                 // leftmost emitted column is a gap whose cost is not charged yet
-    int have_left, left_first_gap;
-    int open_flag;                // right phase: the reference's `open`
-    int n_tiles;
-    int comp;                     // candidate aligns against the reverse-complemented query set
-    int64_t cells;
-};
-
+// Persistent chain kernel (int32 scores).  Per-group state mirrors the locals of
+// GACT() (gact_chain.hpp); every lane of the group carries an identical copy,
+// only the traceback runs on one lane and its results are broadcast.
+//
+// seed_mode: walk every candidate only until its first tile has been consumed
+// (first_tile == false) or the chain is over, then hand the chain state to the
+// main launch (ChainQueues).  The packed-int16 main kernel has no arg-max path;
+// this kernel does all first tiles for it.
 template <int C>
 __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
     KParams kp, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     const gact_candidate *__restrict__ cands, int first_cand, int n,
     int rc_from, int same_file,
-    gact_overlap *__restrict__ out, int *__restrict__ counter,
+    gact_overlap *__restrict__ out, ChainQueues cq, int seed_mode,
     uint32_t *__restrict__ ws_all)
 {
     using G = Geometry<C>;
@@ -172,136 +154,68 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
     const uint8_t *ref_lds_lane = ref_lds_g + (kGroup - 1 - w.gl);
     uint32_t *ws = ws_all + (size_t)w.slot * kp.ws_words;
     const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
-    const int tile = kp.tile_size;
 
     ChainState s;
-    s.comp = 0;
-    s.cand = -1; s.phase = 2;
+    s.comp = 0; s.cand = -1; s.phase = 2;
     bool exhausted = false;
+    __builtin_amdgcn_s_setprio(3);
 
     for (;;) {
         // ---- pick the next tile of this group, finishing / fetching candidates on the way
-        GroupTile gt{0, 0, 0, 0};
-        bool reverse = false;
-        int64_t rp0 = 0, qp0 = 0;
-        bool have_tile = false;
-        for (int guard = 0; guard < 4 && !have_tile; guard++) {
+        TilePick pk;
+        pk.have = false; pk.R = 0; pk.Q = 0; pk.reverse = false; pk.rp0 = 0; pk.qp0 = 0;
+        for (int guard = 0; guard < 3 && !pk.have; guard++) {
             if (s.phase == 2) {
                 if (exhausted) break;
                 int idx = 0;
-                if (w.gl == 0) idx = atomicAdd(counter, 1);
+                if (w.gl == 0) idx = atomicAdd(cq.pop_seed, 1);
                 idx = __shfl(idx, 0, kGroup);
                 if (idx >= n) { exhausted = true; break; }
-                const gact_candidate c = cands[first_cand + idx];
-                s.cand = first_cand + idx;
-                s.comp = (s.cand >= rc_from) ? 1 : 0;      // darwin.cpp:279 passes rev_reads_char
-                const SeqSetDev &cq = s.comp ? qrc : qfwd;
-                s.ref_id = c.ref_id; s.query_id = c.query_id;
-                s.rbase = refs.offsets[c.ref_id];
-                s.qbase = cq.offsets[c.query_id];
-                s.ref_len = (int)(refs.offsets[c.ref_id + 1] - s.rbase);
-                s.query_len = (int)(cq.offsets[c.query_id + 1] - s.qbase);
-                s.ref_pos = c.ref_pos; s.query_pos = c.query_pos;
-                s.rev_ref_pos = c.ref_pos; s.rev_query_pos = c.query_pos;   // gact.cpp:72-73
-                s.abpos = 0; s.bbpos = 0;
-                s.i = 0; s.j = 0; s.first_tile = 1; s.first_tile_score = 0;
-                s.phase = 0; s.brk = 0;
-                s.score = 0; s.pend_gap = 0; s.have_left = 0; s.left_first_gap = 0; s.open_flag = 1;
-                s.n_tiles = 0; s.cells = 0;
+                chain_begin(s, first_cand + idx, cands[first_cand + idx], refs, qfwd, qrc, rc_from);
             }
-            if (s.phase == 0) {
-                // gact.cpp:82
-                if (!s.brk && s.ref_pos > 0 && s.query_pos > 0 && ((s.i > 0 && s.j > 0) || s.first_tile)) {
-                    gt.R = (s.ref_pos > tile) ? tile : s.ref_pos;           // :84-85
-                    gt.Q = (s.query_pos > tile) ? tile : s.query_pos;
-                    gt.first = s.first_tile;
-                    reverse = false;
-                    rp0 = s.rbase + s.ref_pos - gt.R;
-                    qp0 = s.qbase + s.query_pos - gt.Q;
-                    have_tile = true;
-                } else {
-                    // leftmost column has no predecessor: a gap there costs gap_open (open==true at :198)
-                    if (s.pend_gap) s.score += kp.open;
-                    s.pend_gap = 0;
-                    s.abpos = s.ref_pos; s.bbpos = s.query_pos;               // :136-141
-                    s.ref_pos = s.rev_ref_pos; s.query_pos = s.rev_query_pos;
-                    s.i = tile; s.j = tile;
-                    s.open_flag = !(s.have_left && s.left_first_gap);
-                    s.phase = 1; s.brk = 0;
-                }
-            }
-            if (s.phase == 1 && !have_tile) {
-                // gact.cpp:144
-                if (!s.brk && s.ref_pos < s.ref_len && s.query_pos < s.query_len &&
-                    ((s.i > 0 && s.j > 0) || s.first_tile)) {
-                    gt.R = (s.ref_pos + tile < s.ref_len) ? tile : s.ref_len - s.ref_pos;       // :146-147
-                    gt.Q = (s.query_pos + tile < s.query_len) ? tile : s.query_len - s.query_pos;
-                    gt.first = s.first_tile;
-                    reverse = true;
-                    rp0 = s.rbase + s.ref_pos;
-                    qp0 = s.qbase + s.query_pos;
-                    have_tile = true;
-                } else {
-                    if (w.gl == 0) {
-                        gact_overlap o;
-                        o.ref_id = s.ref_id; o.query_id = s.query_id;
-                        o.ab = s.abpos; o.ae = s.ref_pos; o.bb = s.bbpos; o.be = s.query_pos;
-                        o.score = s.score; o.comp = s.comp;
-                        o.emitted = (!(same_file && s.ref_id == s.query_id) && s.score > 0) ? 1 : 0;  // :213
-                        o.first_tile_score = s.first_tile_score;
-                        o.n_tiles = s.n_tiles; o.reserved = 0; o.cells = s.cells;
-                        out[s.cand] = o;
-                    }
-                    s.phase = 2; s.cand = -1;
-                }
-            }
+            pk = chain_pick(s, kp, same_file, out, w.gl == 0);
+            if (!pk.have && seed_mode && w.gl == 0)
+                atomicAdd(cq.seed_cells, (unsigned long long)s.cells);     // finished inside the seed launch
         }
-        if (!__any(have_tile)) {
+        if (!__any(pk.have)) {
             // nobody in this wave has a tile: either all exhausted, or some group
             // still has transitions pending (guard ran out) -- loop again for those
             if (__all(exhausted && s.phase == 2)) break;
             continue;
         }
-        if (!have_tile) { gt.R = 0; gt.Q = 0; gt.first = 0; gt.shift = 0; }
+        GroupTile gt{pk.R, pk.Q, pk.have ? s.first_tile : 0, 0};
 
         const bool active = gt.R > 0 && gt.Q > 0;
         const WavePlan wp = align_starts(last_step<C>(gt.R, gt.Q),
                                          first_pointer_step<C>(gt.R, gt.Q, kp.early, gt.first), active, gt.shift);
         uint32_t qb[C];
-        load_tile<C>(refs, s.comp ? qrc : qfwd, raw, rp0, qp0, gt.R, gt.Q, reverse, w.gl, ref_lds_g, q_lds_g, qb,
-                     gt.shift);
+        load_tile<C>(refs, s.comp ? qrc : qfwd, raw, pk.rp0, pk.qp0, gt.R, gt.Q, pk.reverse, w.gl, ref_lds_g,
+                     q_lds_g, qb, gt.shift);
         wave_sync();
         const bool any_first = __any(gt.first != 0);
 
         PassOut po;
+        __builtin_amdgcn_s_setprio(0);          // throughput work; the serial sections around it run at priority 3
         if (any_first) dp_pass<C, true>(kp, w.gl, ref_lds_lane, qb, gt, wp.T_end, wp.tB, ws, po);
         else           dp_pass<C, false>(kp, w.gl, ref_lds_lane, qb, gt, wp.T_end, wp.tB, ws, po);
+        __builtin_amdgcn_s_setprio(3);
         po.tB -= gt.shift;      // the traceback indexes steps in the tile's own (undelayed) time
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // see align_tiles_kernel
 
         // ---- consume the tile exactly as gact.cpp:95-133 / :158-194 do
-        if (have_tile) {
+        if (pk.have) {
             s.n_tiles++;
             s.cells += (int64_t)gt.R * gt.Q;
             int i0 = gt.R, j0 = gt.Q;
             bool stop = false;
             if (s.first_tile) {
                 i0 = po.bi; j0 = po.bj;
-                if (s.phase == 0) {
-                    s.ref_pos = s.ref_pos - gt.R + po.bi;                    // :100-105
-                    s.query_pos = s.query_pos - gt.Q + po.bj;
-                    s.rev_ref_pos = s.ref_pos; s.rev_query_pos = s.query_pos;
-                } else {
-                    s.ref_pos = s.ref_pos + gt.R - po.bi;                    // :163-166
-                    s.query_pos = s.query_pos + gt.Q - po.bj;
-                }
-                s.first_tile_score = po.best;
-                if (po.best < kp.thr) { stop = true; s.brk = 1; }            // :107-109 / :168-170
+                stop = chain_first_tile(s, kp, gt.R, gt.Q, po.best, po.bi, po.bj);
             }
             int ref_steps = 0, query_steps = 0, nst = 0;
-            int score = s.score, pend_gap = s.pend_gap, open_flag = s.open_flag;
-            int have_left = s.have_left, left_first_gap = s.left_first_gap;
+            ScoreWalk wk;
+            wk.load(s);
             if (!stop && w.gl == 0) {
                 const int phase = s.phase;
                 traceback<C>(ws, i0, j0, po.tB, kp.early, ref_steps, query_steps,
@@ -313,35 +227,20 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
                             const uint32_t qbv = q_lds_g[cj - 1];
                             sub = (rbv == qbv) ? kp.match : kp.mismatch;     // gact.cpp:207
                         }
-                        if (phase == 0) {
-                            // columns arrive right-to-left; the previously emitted one
-                            // now learns its left neighbour
-                            if (pend_gap) score += gap ? kp.ext : kp.open;
-                            if (!have_left) { have_left = 1; left_first_gap = gap; }
-                            if (gap) pend_gap = 1; else { score += sub; pend_gap = 0; }
-                        } else {
-                            if (gap) { score += open_flag ? kp.open : kp.ext; open_flag = 0; }
-                            else { score += sub; open_flag = 1; }
-                        }
+                        wk.column(phase, gap, sub, kp);
                         nst++;
                     });
             }
-            // broadcast lane 0's results to the group
-            ref_steps = __shfl(ref_steps, 0, kGroup);
-            query_steps = __shfl(query_steps, 0, kGroup);
-            nst = __shfl(nst, 0, kGroup);
-            s.score = __shfl(score, 0, kGroup);
-            s.pend_gap = __shfl(pend_gap, 0, kGroup);
-            s.open_flag = __shfl(open_flag, 0, kGroup);
-            s.have_left = __shfl(have_left, 0, kGroup);
-            s.left_first_gap = __shfl(left_first_gap, 0, kGroup);
-            if (nst > 0) s.first_tile = 0;                                   // :112 / :173
-            s.i = query_steps; s.j = ref_steps;                              // gact.cpp's i counts query bases
-            if (!stop) {
-                if (s.phase == 0) { s.ref_pos -= ref_steps; s.query_pos -= query_steps; }   // :132-133
-                else              { s.ref_pos += ref_steps; s.query_pos += query_steps; }   // :193-194
-            } else {
-                s.i = 0; s.j = 0;
+            chain_advance(s, stop, wk, ref_steps, query_steps, nst, 0);
+            if (seed_mode && !s.first_tile) {
+                // first tile done: the rest of the chain belongs to the main launch
+                if (w.gl == 0) {
+                    cq.states[s.cand] = s;
+                    const int slot = atomicAdd(cq.live_count, 1);
+                    cq.live[slot] = s.cand;
+                    atomicAdd(cq.seed_cells, (unsigned long long)s.cells);
+                }
+                s.phase = 2;
             }
         }
         wave_sync();

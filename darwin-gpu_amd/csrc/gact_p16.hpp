@@ -1,0 +1,405 @@
+// gact_p16.hpp -- packed-int16 variant of the chain kernel's DP pass.
+//
+// Same decomposition as gact_device.hpp (16 lanes per tile, C columns per
+// lane, anti-diagonal wavefront, DPP row_shr across lanes), but every 32-bit
+// register carries TWO tiles: tile A in the low half-word, tile B in the high
+// one, so a wave works on 8 tiles and each score instruction (v_pk_add_i16,
+// v_pk_max_i16, v_pk_mad_i16) serves two cells.  The traceback-pointer masks
+// still come from one compare per cell, now SDWA half-word compares
+// (v_cmp_*_i16_sdwa src_sel:WORD_0/1).
+//
+// Valid only while every intermediate fits int16 (p16_scoring_ok); the engine
+// falls back to the int32 kernel otherwise.  No arg-max here: first tiles are
+// done by the int32 kernel's seed launch (gact_kernels.hpp).
+#pragma once
+
+#include "gact_chain.hpp"
+
+namespace gact {
+
+// Diagnostic build only (-DGACT_STAMPS): per-phase shader-clock totals of the main kernel,
+// summed over waves into g_stamps (never read by the kernel itself).
+#ifdef GACT_STAMPS
+__device__ unsigned long long g_stamps[8];
+#define GACT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define GACT_ACC(slot, t0, t1) stamp_acc[slot] += (t1) - (t0)
+#else
+#define GACT_STAMP(var)
+#define GACT_ACC(slot, t0, t1)
+#endif
+
+constexpr int kNegInf16 = -16384;
+constexpr int kSlots = 2;                  // tiles per 16-lane group (low / high half-word)
+
+// scoring constants replicated into both half-words
+struct P16Consts {
+    uint32_t match, nd /* mismatch - match */, open, ext, ninf, one;
+};
+
+__host__ __device__ inline uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
+
+// every value of the recurrence is in [gap_open, tile*match] once row 1 is
+// reached; the -INF sentinel only ever gets one gap_extend added to it
+__host__ inline bool p16_scoring_ok(int tile, int match, int mismatch, int open, int ext)
+{
+    return match >= 0 && (long long)match * (tile + 2) <= 12000 && mismatch >= -4000 && open >= -4000 &&
+           ext >= -4000 && open - ext > kNegInf16 + 64;
+}
+
+#define GACT_PK2(name, op)                                                                        \
+    __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b)                               \
+    {                                                                                             \
+        uint32_t r;                                                                               \
+        asm(op " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));                                         \
+        return r;                                                                                 \
+    }                                                                                             \
+    __device__ __forceinline__ uint32_t name##_s(uint32_t a, uint32_t s)                           \
+    {                                                                                             \
+        uint32_t r;                                                                               \
+        asm(op " %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));                                         \
+        return r;                                                                                 \
+    }
+GACT_PK2(pk_add, "v_pk_add_i16")
+GACT_PK2(pk_max, "v_pk_max_i16")
+GACT_PK2(pk_minu, "v_pk_min_u16")
+#undef GACT_PK2
+
+__device__ __forceinline__ uint32_t pk_max0(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(a));
+    return r;
+}
+// a*s + c per half-word
+__device__ __forceinline__ uint32_t pk_mad_s(uint32_t a, uint32_t s, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c));
+    return r;
+}
+
+// lane masks of half-word compares
+#define GACT_CMP16(name, op, sel)                                                                 \
+    __device__ __forceinline__ uint64_t name(uint32_t a, uint32_t b)                               \
+    {                                                                                             \
+        uint64_t m;                                                                               \
+        asm(op " %0, %1, %2 src0_sel:" sel " src1_sel:" sel : "=s"(m) : "v"(a), "v"(b));          \
+        return m;                                                                                 \
+    }
+GACT_CMP16(ge_lo, "v_cmp_ge_i16_sdwa", "WORD_0")
+GACT_CMP16(ge_hi, "v_cmp_ge_i16_sdwa", "WORD_1")
+GACT_CMP16(gt_lo, "v_cmp_gt_i16_sdwa", "WORD_0")
+GACT_CMP16(gt_hi, "v_cmp_gt_i16_sdwa", "WORD_1")
+GACT_CMP16(eq_lo, "v_cmp_eq_u16_sdwa", "WORD_0")
+GACT_CMP16(eq_hi, "v_cmp_eq_u16_sdwa", "WORD_1")
+#undef GACT_CMP16
+
+template <int C> struct GeometryP16 {
+    static constexpr int kTileMax = C * kGroup;
+    static constexpr int kMaxSteps = kTileMax + kGroup;
+    // ref stream: one 16-bit entry per step-row, byte 0 = tile A's base, byte 1 = tile B's
+    static constexpr int kRefEntries = kGroup + kMaxSteps + kTileMax + kGroup;
+    static constexpr int kRefBytes = kRefEntries * 2;
+    static constexpr int kQueryBytes = kTileMax * kSlots;
+    static constexpr int kGroupLds = (kRefBytes + kQueryBytes + 15) & ~15;
+};
+
+// ---------------------------------------------------------------------------
+// One pass of a wave: 4 groups x 2 tiles.  ref16 is this lane's view of the
+// group's ref stream: entry [t] holds the bases of step-row (t - gl) of both
+// tiles (each tile's own start delay is folded in when the stream is written).
+template <int C>
+__device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
+                                            const uint16_t *__restrict__ ref16,
+                                            const uint32_t (&qb)[C],
+                                            const int T_end, const int tB,
+                                            uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB)
+{
+    uint32_t Hm[C], Mo[C], Iup[C];          // H+match, M+open, I of the previous row (both tiles)
+    uint32_t accA[C], accB[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        Hm[c] = kc.match;                   // H[0][j] = 0
+        Mo[c] = kc.open;                    // M[0][j] + gap_open
+        Iup[c] = kc.ninf;                   // I[0][j] = -INF
+        accA[c] = 0; accB[c] = 0;
+    }
+    uint32_t Mo_last = kc.open, D_last = kc.ninf, Hm_last = kc.match;
+    uint32_t Hm_left_prev = kc.match;
+    const uint32_t zero = 0;
+
+    auto unpack = [](uint32_t w) { return (w & 0xffu) | ((w & 0xff00u) << 8); };
+    uint32_t rbp = unpack(ref16[1]);
+
+    auto step = [&](const int t, auto ptr_tag) {
+        constexpr bool PTR = decltype(ptr_tag)::value;
+        const uint32_t w_next = ref16[t + 1];
+
+        const uint32_t Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)kc.open);
+        const uint32_t Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)kc.ninf);
+        const uint32_t Hl = (uint32_t)dpp_row_shr1((int)Hm_last, (int)kc.match);
+        uint32_t Hd = Hm_left_prev;
+        Hm_left_prev = Hl;
+
+        uint32_t M[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            // sub = (q==r) ? match : mismatch, as match + (q!=r)*(mismatch-match)   (align.cpp:134)
+            const uint32_t neq = pk_minu_s(qb[c] ^ rbp, kc.one);
+            const uint32_t Mx = pk_mad_s(neq, kc.nd, Hd);          // (H[i-1][j-1] + match) + neq*nd
+            Hd = Hm[c];
+            M[c] = pk_max0(Mx);                                     // :145-147
+            const uint32_t Ie = pk_add_s(Iup[c], kc.ext);           // ins_extend :150
+            if (PTR) {                                              // ins_open >= ins_extend :170
+                accA[c] = shl1_insert(accA[c], ge_lo(Mo[c], Ie));
+                accB[c] = shl1_insert(accB[c], ge_hi(Mo[c], Ie));
+            }
+            Iup[c] = pk_max(Mo[c], Ie);                             // :154
+            Mo[c] = pk_add_s(M[c], kc.open);
+        }
+        uint32_t Ml = Ml0, Dl = Dl0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t De = pk_add_s(Dl, kc.ext);               // del_extend :152
+            const uint32_t D = pk_max(Ml, De);                      // :156
+            const uint32_t H = pk_max(pk_max(M[c], Iup[c]), D);     // :158-160 (M >= 0)
+            if (PTR) {
+                {   // tile A
+                    const uint64_t nz = gt_lo(H, zero), a = eq_lo(M[c], H), b = eq_lo(Iup[c], H);
+                    uint32_t x = shl1_insert(accA[c], ge_lo(Ml, De));          // :171
+                    x = shl1_insert(x, nz & (a | b));
+                    accA[c] = shl1_insert(x, nz & (a | ~b));
+                }
+                {   // tile B
+                    const uint64_t nz = gt_hi(H, zero), a = eq_hi(M[c], H), b = eq_hi(Iup[c], H);
+                    uint32_t x = shl1_insert(accB[c], ge_hi(Ml, De));
+                    x = shl1_insert(x, nz & (a | b));
+                    accB[c] = shl1_insert(x, nz & (a | ~b));
+                }
+            }
+            Hm[c] = pk_add_s(H, kc.match);
+            Ml = Mo[c];
+            Dl = D;
+        }
+        Mo_last = Ml;
+        D_last = Dl;
+        Hm_last = Hm[C - 1];
+        rbp = unpack(w_next);
+    };
+
+    int t = 1;
+    for (; t < tB && t <= T_end; t++) step(t, std::false_type{});
+    uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
+    uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
+    int k = 0;
+    for (; t <= T_end; t++, k++) {
+        step(t, std::true_type{});
+        if ((k & 7) == 7) {
+#pragma unroll
+            for (int q = 0; q < C / 4; q++) {
+                qA[q * kGroup] = make_uint4(accA[4 * q], accA[4 * q + 1], accA[4 * q + 2], accA[4 * q + 3]);
+                qB[q * kGroup] = make_uint4(accB[4 * q], accB[4 * q + 1], accB[4 * q + 2], accB[4 * q + 3]);
+            }
+            qA += (C / 4) * kGroup;
+            qB += (C / 4) * kGroup;
+        }
+    }
+    if (k & 7) {
+        const int sh = 4 * (8 - (k & 7));
+#pragma unroll
+        for (int q = 0; q < C / 4; q++) {
+            qA[q * kGroup] = make_uint4(accA[4 * q] << sh, accA[4 * q + 1] << sh, accA[4 * q + 2] << sh,
+                                        accA[4 * q + 3] << sh);
+            qB[q * kGroup] = make_uint4(accB[4 * q] << sh, accB[4 * q + 1] << sh, accB[4 * q + 2] << sh,
+                                        accB[4 * q + 3] << sh);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Loads the two tiles of a group: packed query codes into qb, ref stream and
+// query bytes into LDS.  The ref stream must have been filled with pad bytes.
+struct PairTile {
+    int R[kSlots], Q[kSlots], shift[kSlots];
+    bool reverse[kSlots];
+    int64_t rp0[kSlots], qp0[kSlots];
+    int comp[kSlots];
+};
+
+template <int C>
+__device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc, bool raw,
+                                          const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8,
+                                          uint32_t (&qb)[C])
+{
+    using G = GeometryP16<C>;
+    // pad the whole stream: rows in front of row 1 (skew + start delay) and behind row R
+    uint32_t *ref32 = reinterpret_cast<uint32_t *>(ref8);
+    for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = 0xffffffffu;
+    wave_sync();
+#pragma unroll
+    for (int c = 0; c < C; c++) qb[c] = 0;
+#pragma unroll
+    for (int h = 0; h < kSlots; h++) {
+        const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
+        const int R = pt.R[h], Q = pt.Q[h];
+        uint8_t *rrow = ref8 + (kGroup + pt.shift[h]) * 2 + h;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int d = gl * C + c;
+            uint32_t qv = kQueryPad;
+            if (d < R) rrow[d * 2] = (uint8_t)fetch_base(rs, pt.reverse[h] ? pt.rp0[h] + (R - 1 - d) : pt.rp0[h] + d, raw);
+            if (d < Q) qv = fetch_base(qs, pt.reverse[h] ? pt.qp0[h] + (Q - 1 - d) : pt.qp0[h] + d, raw);
+            q8[h * G::kTileMax + d] = (uint8_t)qv;
+            qb[c] |= qv << (16 * h);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Persistent main kernel: every group carries two candidates (slot A / slot B).
+template <int C>
+__global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
+    KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
+    int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
+    uint32_t *__restrict__ ws_all)
+{
+    using G = GeometryP16<C>;
+    constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
+    __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
+
+    const WaveCtx w = wave_ctx();
+    const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
+    uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
+    uint8_t *q8 = ref8 + G::kRefBytes;
+    const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (kGroup - 1 - w.gl);
+    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
+    uint32_t *wsB = wsA + kp.ws_words;
+    const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
+    const int n_live = *cq.live_count;
+
+    ChainState *st = chain_lds[group_in_block];
+    if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
+    wave_sync();
+    bool exhausted = false;
+    __builtin_amdgcn_s_setprio(3);
+#ifdef GACT_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    for (;;) {
+        GACT_STAMP(t_a);
+        // ---- control phase: both slots pick their next tile (chain state lives in LDS
+        //      between passes so that the DP loop owns the register file)
+        PairTile pt;
+        bool have[kSlots];
+        int Tend_h[kSlots], tB_h[kSlots];
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            ChainState s = st[h];
+            TilePick pk;
+            pk.have = false; pk.R = 0; pk.Q = 0; pk.reverse = false; pk.rp0 = 0; pk.qp0 = 0;
+            for (int guard = 0; guard < 3 && !pk.have; guard++) {
+                if (s.phase == 2) {
+                    if (exhausted) break;
+                    int idx = 0;
+                    if (w.gl == 0) idx = atomicAdd(cq.pop_main, 1);
+                    idx = __shfl(idx, 0, kGroup);
+                    if (idx >= n_live) { exhausted = true; break; }
+                    s = cq.states[cq.live[idx]];
+                }
+                pk = chain_pick(s, kp, same_file, out, w.gl == 0);
+            }
+            have[h] = pk.have;
+            pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
+            pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
+            Tend_h[h] = last_step<C>(pk.R, pk.Q);
+            tB_h[h] = first_pointer_step<C>(pk.R, pk.Q, kp.early, false);
+            wave_sync();
+            if (w.gl == 0) st[h] = s;
+            wave_sync();
+        }
+        const bool any_here = have[0] | have[1];
+        if (!__any(any_here)) {
+            if (__all(exhausted && st[0].phase == 2 && st[1].phase == 2)) break;
+            continue;
+        }
+        // common end / common pointer start over the wave's 8 tiles (align_starts)
+        const int T_end = wave_max4(imax(have[0] ? Tend_h[0] : 0, have[1] ? Tend_h[1] : 0));
+        const int reach0 = have[0] ? tB_h[0] + (T_end - Tend_h[0]) : 0x7fffffff;
+        const int reach1 = have[1] ? tB_h[1] + (T_end - Tend_h[1]) : 0x7fffffff;
+        const int tB = wave_min4(imin(reach0, reach1));
+        pt.shift[0] = have[0] ? imax(0, tB - tB_h[0]) : 0;
+        pt.shift[1] = have[1] ? imax(0, tB - tB_h[1]) : 0;
+
+        GACT_STAMP(t_b);
+        uint32_t qb[C];
+        load_pair<C>(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
+        wave_sync();
+        GACT_STAMP(t_c);
+
+        // the DP pass is throughput work; everything else in this loop is a short serial
+        // chain (traceback, chain bookkeeping, loads) that must not queue behind other
+        // waves' DP instructions: run it at raised issue priority
+        __builtin_amdgcn_s_setprio(0);
+        dp_pass_p16<C>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
+        __builtin_amdgcn_s_setprio(3);
+        GACT_STAMP(t_d);
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pointer stores -> L2 before the sc1 loads
+        GACT_STAMP(t_e);
+
+        // ---- traceback: lane h of the group walks slot h, all walkers of the wave in one loop
+        int ref_steps = 0, query_steps = 0, nst = 0;
+        ScoreWalk wk;
+        wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
+        {
+            const int h = w.gl & 1;
+            const bool mine = (w.gl < kSlots) && (h ? have[1] : have[0]);
+            if (mine) {
+                const ChainState &s = st[h];
+                wk.load(s);
+                const int phase = s.phase;
+                const int sh = h ? pt.shift[1] : pt.shift[0];
+                const uint8_t *rrow = ref8 + (kGroup + sh) * 2 + h;
+                const uint8_t *qrow = q8 + h * G::kTileMax;
+                traceback_cached<C>(h ? wsB : wsA, tb_lds[group_in_block][h], h ? pt.R[1] : pt.R[0],
+                                    h ? pt.Q[1] : pt.Q[0], tB - sh, kp.early, ref_steps, query_steps,
+                    [&](int state, int ci, int cj) {
+                        const bool gap = (state != GACT_STATE_M);
+                        int sub = 0;
+                        if (!gap) sub = (rrow[(ci - 1) * 2] == qrow[cj - 1]) ? kp.match : kp.mismatch;   // gact.cpp:207
+                        wk.column(phase, gap, sub, kp);
+                        nst++;
+                    });
+            }
+        }
+        GACT_STAMP(t_f);
+        // ---- consume (gact.cpp:111-133 / :172-194); non-first tiles only
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            if (have[h]) {
+                ChainState s = st[h];
+                s.n_tiles++;
+                s.cells += (int64_t)pt.R[h] * pt.Q[h];
+                chain_advance(s, false, wk, ref_steps, query_steps, nst, h);
+                wave_sync();
+                if (w.gl == 0) st[h] = s;
+            }
+            wave_sync();
+        }
+        GACT_STAMP(t_g);
+        GACT_ACC(0, t_a, t_b); GACT_ACC(1, t_b, t_c); GACT_ACC(2, t_c, t_d); GACT_ACC(3, t_d, t_e);
+        GACT_ACC(4, t_e, t_f); GACT_ACC(5, t_f, t_g);
+#ifdef GACT_STAMPS
+        stamp_acc[6] += 1; stamp_acc[7] += (unsigned long long)(T_end - tB + 1);
+#endif
+    }
+#ifdef GACT_STAMPS
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 8; k++) atomicAdd(&g_stamps[k], stamp_acc[k]);
+#endif
+}
+
+}  // namespace gact

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # darwin-gp
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp")] + \
+           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
 SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2
@@ -40,6 +40,11 @@ class Params(C.Structure):
 class DeviceInfo(C.Structure):
     _fields_ = [("compute_units", C.c_int32), ("clock_mhz", C.c_int32), ("waves_per_cu", C.c_int32),
                 ("wave_size", C.c_int32), ("hbm_bytes", C.c_int64), ("arch", C.c_char * 32)]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("seed_ms", C.c_float), ("main_ms", C.c_float),
+                ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_cells", C.c_int64)]
 
 
 class GactHipError(RuntimeError):
@@ -108,6 +113,7 @@ def load():
     L.gact_hip_candidates_fetch.argtypes = [vp, C.c_int, i32, vp]
     L.gact_hip_sync.argtypes = [vp, C.c_int]
     L.gact_hip_last_kernel_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+    L.gact_hip_last_run_stats.argtypes = [vp, C.c_int, C.POINTER(RunStats)]
     L.gact_hip_device_overlaps.argtypes = [vp, C.c_int]
     L.gact_hip_device_overlaps.restype = vp
     L.gact_hip_stream.argtypes = [vp, C.c_int]
@@ -117,7 +123,7 @@ def load():
     L.gact_hip_format_overlap.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
     for name in ("create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
                  "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range", "candidates_run_mixed",
-                 "candidates_fetch", "sync", "last_kernel_ms", "format_overlap"):
+                 "candidates_fetch", "sync", "last_kernel_ms", "last_run_stats", "format_overlap"):
         getattr(L, "gact_hip_" + name).restype = C.c_int
     _lib = L
     return L
@@ -127,7 +133,7 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_upload_seqs", "gact_hip_align_tiles", "gact_hip_align_tiles_inline",
            "gact_hip_extend_candidates", "gact_hip_candidates_upload", "gact_hip_candidates_run",
            "gact_hip_candidates_run_range", "gact_hip_candidates_run_mixed", "gact_hip_candidates_fetch", "gact_hip_sync",
-           "gact_hip_last_kernel_ms", "gact_hip_device_overlaps", "gact_hip_stream",
+           "gact_hip_last_kernel_ms", "gact_hip_last_run_stats", "gact_hip_device_overlaps", "gact_hip_stream",
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap")
 
 
@@ -244,6 +250,12 @@ class Engine:
         ms = C.c_float()
         self._check(self.L.gact_hip_last_kernel_ms(self.h, slot, C.byref(ms)))
         return float(ms.value)
+
+    def last_run_stats(self, slot=0):
+        st = RunStats()
+        self._check(self.L.gact_hip_last_run_stats(self.h, slot, C.byref(st)))
+        return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
+                "packed16": bool(st.packed16), "handed_off": st.handed_off, "seed_cells": st.seed_cells}
 
     def measure_valu_rate(self):
         v = C.c_double()

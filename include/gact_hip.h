@@ -192,6 +192,18 @@ int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, i
 int gact_hip_sync(gact_hip_engine *e, int slot);
 /* HIP-event time of the last kernel launched on this slot's stream, in ms */
 int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);
+/* How the last candidates_run* on this slot was executed.  With the default
+ * scoring the chain runs as two launches: a seed launch (int32 kernel, first
+ * tile of every candidate, arg-max + full pointer matrix) and the main launch
+ * (packed-int16 kernel, every later tile). */
+typedef struct {
+    float total_ms, seed_ms, main_ms;   /* HIP events on the slot's stream */
+    int32_t packed16;                   /* 1: seed + packed-int16 main launch, 0: one int32 launch */
+    int32_t handed_off;                 /* candidates the main launch continued */
+    int64_t seed_cells;                 /* DP cells executed by the seed launch */
+} gact_hip_run_stats;
+int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
+
 /* device address of the slot's gact_overlap array (for an RCCL gather) */
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);
 /* the slot's hipStream_t as an opaque pointer */

@@ -38,6 +38,37 @@ def _run(rs, cf, cr, oracle, scoring=(1, -1, -1, -1), tile=320, overlap=120, thr
     return total
 
 
+@pytest.fixture(params=["packed16", "int32"], autouse=True)
+def kernel_family(request, monkeypatch):
+    """every chain test runs twice: seed + packed-int16 main launch (default), and the int32 kernel alone"""
+    if request.param == "int32":
+        monkeypatch.setenv("GACT_HIP_FORCE_INT32", "1")
+    else:
+        monkeypatch.delenv("GACT_HIP_FORCE_INT32", raising=False)
+    return request.param
+
+
+def test_kernel_family_is_the_one_asked_for(kernel_family):
+    from gact_amd import engine, synth
+    rs = synth.simulate_reads(9000, n_reads=6, seed=2, mean_len=3000, sd_len=300, min_len=1500, max_len=4000)
+    cf, _ = synth.synth_candidates(rs, seed=3, min_overlap=300)
+    eng = engine.Engine()
+    cat, offs = rs.concat()
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
+    eng.extend(cf)
+    st = eng.last_run_stats()
+    assert st["packed16"] == (kernel_family == "packed16")
+    if st["packed16"]:
+        assert 0 < st["handed_off"] <= len(cf) and st["seed_cells"] > 0
+    eng.close()
+    # scoring outside the int16-safe range must fall back to int32 by itself
+    eng = engine.Engine(scoring=(100, -90, -200, -50))
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
+    eng.extend(cf)
+    assert eng.last_run_stats()["packed16"] is False
+    eng.close()
+
+
 def test_chain_small(oracle):
     from gact_amd import synth
     rs = synth.simulate_reads(30000, n_reads=24, seed=5, mean_len=5000, sd_len=1500, min_len=800, max_len=9000)
@@ -45,7 +76,7 @@ def test_chain_small(oracle):
     assert _run(rs, cf, cr, oracle) > 100
 
 
-@pytest.mark.parametrize("scoring", [(2, -3, -5, -2), (5, -4, -10, -1), (1, -1, -2, -1)])
+@pytest.mark.parametrize("scoring", [(2, -3, -5, -2), (5, -4, -10, -1), (1, -1, -2, -1), (30, -40, -70, -20)])
 def test_chain_other_scoring(oracle, scoring):
     from gact_amd import synth
     rs = synth.simulate_reads(20000, n_reads=16, seed=8, mean_len=4000, sd_len=1000, min_len=800, max_len=8000)

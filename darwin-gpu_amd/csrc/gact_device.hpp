@@ -434,7 +434,10 @@ __device__ __forceinline__ void tb_refill(const uint32_t *ws, uint32_t *scratch,
     for (int n = 0; n < 12; n++) dst[n] = r[n];
 }
 
-template <int C>
+// FMT 0: the int32 kernels' word, 8 rows x 4 bits {ins_open>=ins_extend, del_open>=del_extend, op}.
+// FMT 1: the packed kernel's word, low half 8 rows x 2 bits op code (0 ZERO 1 MATCH 2 INSERT 3 DELETE),
+//        high half 8 rows x 2 bits {ins_open<ins_extend, del_open<del_extend}.  Both return the FMT 0 nibble.
+template <int C, int FMT>
 __device__ __forceinline__ uint32_t tb_lookup(const uint32_t *scratch, int i, int j, int tB, const TbRegion<C> &rg)
 {
     const int l = (j - 1) / C;
@@ -444,13 +447,17 @@ __device__ __forceinline__ uint32_t tb_lookup(const uint32_t *scratch, int i, in
     const int lev = (k >> 3) - (sl ? rg.fbase[1] : rg.fbase[0]);
     const int qq = (c >> 2) - (sl ? C / 4 - 3 : rg.qbase0);
     const uint32_t w = scratch[(((sl * 2 + lev) * 3 + qq) << 2) + (c & 3)];
-    return (w >> (28 - 4 * (k & 7))) & 15u;
+    if (FMT == 0) return (w >> (28 - 4 * (k & 7))) & 15u;
+    const int sh = 14 - 2 * (k & 7);
+    const uint32_t code = (w >> sh) & 3u, nfl = ~(w >> (sh + 16)) & 3u;
+    const uint32_t state = code ? 4u - code : 0u;              // -> align.h:23 numbering Z0 D1 I2 M3
+    return state | (nfl << 2);                                 // bit3 ins flag, bit2 del flag
 }
 
 // Same walk as traceback() above (align.cpp:185-230); `scratch` is this lane's
 // kTbScratchWords dwords of LDS.  All lanes that enter take the same number of
 // steps between refills, so the refill branch is uniform among them.
-template <int C, class Emit>
+template <int C, int FMT, class Emit>
 __device__ __forceinline__ void traceback_cached(const uint32_t *ws, uint32_t *scratch, int i, int j, int tB,
                                                  int early, int &ref_steps, int &query_steps, Emit &&emit)
 {
@@ -461,7 +468,7 @@ __device__ __forceinline__ void traceback_cached(const uint32_t *ws, uint32_t *s
     int since = 0;
     if (i >= 1 && j >= 1 && early > 0) {
         tb_refill<C>(ws, scratch, i, j, tB, rg);
-        nib = tb_lookup<C>(scratch, i, j, tB, rg);
+        nib = tb_lookup<C, FMT>(scratch, i, j, tB, rg);
         state = nib & 3;
     }
     while (state != GACT_STATE_Z) {
@@ -477,7 +484,7 @@ __device__ __forceinline__ void traceback_cached(const uint32_t *ws, uint32_t *s
             tb_refill<C>(ws, scratch, i, j, tB, rg);
             since = 0;
         }
-        nib = tb_lookup<C>(scratch, i, j, tB, rg);
+        nib = tb_lookup<C, FMT>(scratch, i, j, tB, rg);
         state = (next < 0) ? (int)(nib & 3) : next;
     }
     ref_steps = is;

@@ -78,6 +78,44 @@ __device__ __forceinline__ uint32_t pk_mad_s(uint32_t a, uint32_t s, uint32_t c)
     return r;
 }
 
+// per half-word: a - b, x >> 15 (logical), min(x, 1), a*K + c with a small constant K in both halves
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_sign(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_lshrrev_b16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_min1(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad_vvv(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_shl_add2(uint32_t acc, uint32_t bit)    // acc*2 + bit
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(bit));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_shl_add4(uint32_t acc, uint32_t code)   // acc*4 + code
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(acc), "v"(code));
+    return r;
+}
+
 // lane masks of half-word compares
 #define GACT_CMP16(name, op, sel)                                                                 \
     __device__ __forceinline__ uint64_t name(uint32_t a, uint32_t b)                               \
@@ -116,17 +154,20 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                                             uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB)
 {
     uint32_t Hm[C], Mo[C], Iup[C];          // H+match, M+open, I of the previous row (both tiles)
-    uint32_t accA[C], accB[C];
+    // Pointer bits, packed for both tiles (tile A low half-word, tile B high), 8 rows per half-word:
+    //   accO  2 bits/row  op code  0 ZERO, 1 MATCH, 2 INSERT, 3 DELETE   = nz * (1 + na * (1 + nb))
+    //   accF  2 bits/row  {ins_open < ins_extend, del_open < del_extend}  (the complements of align.cpp:170-171)
+    // built arithmetically: a comparison is the sign bit of a packed difference, or min(difference, 1)
+    uint32_t accO[C], accF[C];
 #pragma unroll
     for (int c = 0; c < C; c++) {
         Hm[c] = kc.match;                   // H[0][j] = 0
         Mo[c] = kc.open;                    // M[0][j] + gap_open
         Iup[c] = kc.ninf;                   // I[0][j] = -INF
-        accA[c] = 0; accB[c] = 0;
+        accO[c] = 0; accF[c] = 0;
     }
     uint32_t Mo_last = kc.open, D_last = kc.ninf, Hm_last = kc.match;
     uint32_t Hm_left_prev = kc.match;
-    const uint32_t zero = 0;
 
     auto unpack = [](uint32_t w) { return (w & 0xffu) | ((w & 0xff00u) << 8); };
     uint32_t rbp = unpack(ref16[1]);
@@ -145,15 +186,12 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
 #pragma unroll
         for (int c = 0; c < C; c++) {
             // sub = (q==r) ? match : mismatch, as match + (q!=r)*(mismatch-match)   (align.cpp:134)
-            const uint32_t neq = pk_minu_s(qb[c] ^ rbp, kc.one);
+            const uint32_t neq = pk_min1(qb[c] ^ rbp);
             const uint32_t Mx = pk_mad_s(neq, kc.nd, Hd);          // (H[i-1][j-1] + match) + neq*nd
             Hd = Hm[c];
             M[c] = pk_max0(Mx);                                     // :145-147
             const uint32_t Ie = pk_add_s(Iup[c], kc.ext);           // ins_extend :150
-            if (PTR) {                                              // ins_open >= ins_extend :170
-                accA[c] = shl1_insert(accA[c], ge_lo(Mo[c], Ie));
-                accB[c] = shl1_insert(accB[c], ge_hi(Mo[c], Ie));
-            }
+            if (PTR) accF[c] = pk_shl_add2(accF[c], pk_sign(pk_sub(Mo[c], Ie)));   // ins_open < ins_extend  (:170)
             Iup[c] = pk_max(Mo[c], Ie);                             // :154
             Mo[c] = pk_add_s(M[c], kc.open);
         }
@@ -164,18 +202,13 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
             const uint32_t D = pk_max(Ml, De);                      // :156
             const uint32_t H = pk_max(pk_max(M[c], Iup[c]), D);     // :158-160 (M >= 0)
             if (PTR) {
-                {   // tile A
-                    const uint64_t nz = gt_lo(H, zero), a = eq_lo(M[c], H), b = eq_lo(Iup[c], H);
-                    uint32_t x = shl1_insert(accA[c], ge_lo(Ml, De));          // :171
-                    x = shl1_insert(x, nz & (a | b));
-                    accA[c] = shl1_insert(x, nz & (a | ~b));
-                }
-                {   // tile B
-                    const uint64_t nz = gt_hi(H, zero), a = eq_hi(M[c], H), b = eq_hi(Iup[c], H);
-                    uint32_t x = shl1_insert(accB[c], ge_hi(Ml, De));
-                    x = shl1_insert(x, nz & (a | b));
-                    accB[c] = shl1_insert(x, nz & (a | ~b));
-                }
+                accF[c] = pk_shl_add2(accF[c], pk_sign(pk_sub(Ml, De)));       // del_open < del_extend  (:171)
+                // :162-168 with M >= 0: ZERO iff H == 0, else MATCH iff M == H, else INSERT iff I == H, else DELETE
+                const uint32_t nz = pk_min1(H);
+                const uint32_t na = pk_min1(pk_sub(H, M[c]));       // M < H
+                const uint32_t nb = pk_min1(pk_sub(H, Iup[c]));     // I < H
+                const uint32_t o = pk_mad_vvv(na, nb, na);          // 0 MATCH, 1 INSERT, 2 DELETE
+                accO[c] = pk_shl_add4(accO[c], pk_mad_vvv(nz, o, nz));
             }
             Hm[c] = pk_add_s(H, kc.match);
             Ml = Mo[c];
@@ -187,6 +220,10 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         rbp = unpack(w_next);
     };
 
+    // tile A's word = {accF.lo, accO.lo}, tile B's = {accF.hi, accO.hi}: flags in the high half-word
+    auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
+    auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
+
     int t = 1;
     for (; t < tB && t <= T_end; t++) step(t, std::false_type{});
     uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
@@ -197,21 +234,25 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         if ((k & 7) == 7) {
 #pragma unroll
             for (int q = 0; q < C / 4; q++) {
-                qA[q * kGroup] = make_uint4(accA[4 * q], accA[4 * q + 1], accA[4 * q + 2], accA[4 * q + 3]);
-                qB[q * kGroup] = make_uint4(accB[4 * q], accB[4 * q + 1], accB[4 * q + 2], accB[4 * q + 3]);
+                qA[q * kGroup] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
+                                            wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
+                qB[q * kGroup] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
+                                            wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
             }
             qA += (C / 4) * kGroup;
             qB += (C / 4) * kGroup;
         }
     }
     if (k & 7) {
-        const int sh = 4 * (8 - (k & 7));
+        // left-justify the partial block: each half-word holds 2 bits per stored row
+        const int sh = 2 * (8 - (k & 7));
+        auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
 #pragma unroll
         for (int q = 0; q < C / 4; q++) {
-            qA[q * kGroup] = make_uint4(accA[4 * q] << sh, accA[4 * q + 1] << sh, accA[4 * q + 2] << sh,
-                                        accA[4 * q + 3] << sh);
-            qB[q * kGroup] = make_uint4(accB[4 * q] << sh, accB[4 * q + 1] << sh, accB[4 * q + 2] << sh,
-                                        accB[4 * q + 3] << sh);
+            qA[q * kGroup] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+                                        just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
+            qB[q * kGroup] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+                                        just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
         }
     }
 }
@@ -364,7 +405,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
                 const int sh = h ? pt.shift[1] : pt.shift[0];
                 const uint8_t *rrow = ref8 + (kGroup + sh) * 2 + h;
                 const uint8_t *qrow = q8 + h * G::kTileMax;
-                traceback_cached<C>(h ? wsB : wsA, tb_lds[group_in_block][h], h ? pt.R[1] : pt.R[0],
+                traceback_cached<C, 1>(h ? wsB : wsA, tb_lds[group_in_block][h], h ? pt.R[1] : pt.R[0],
                                     h ? pt.Q[1] : pt.Q[0], tB - sh, kp.early, ref_steps, query_steps,
                     [&](int state, int ci, int cj) {
                         const bool gap = (state != GACT_STATE_M);

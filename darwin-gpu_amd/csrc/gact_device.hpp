@@ -103,11 +103,24 @@ __device__ __forceinline__ int wave_min4(int v)
 }
 
 // one base of a resident set at concat position pos
-__device__ __forceinline__ uint32_t fetch_base(const SeqSetDev &s, int64_t pos, bool raw)
+template <bool RAW>
+__device__ __forceinline__ uint32_t fetch_base(const SeqSetDev &s, int64_t pos)
 {
-    if (raw) return s.raw[pos];
+    if (RAW) return s.raw[pos];
     const uint32_t w = s.packed[pos >> 4];
     return (w >> ((uint32_t)(pos & 15) * 2u)) & 3u;
+}
+
+// Position of DP index d (0-based) in a slice of `len` bases starting at p0: the
+// slice is read back to front when `reverse` (align.cpp:130-131).  d is clamped
+// into the slice (an empty slice reads its own first position, which always
+// lies inside the set's padded allocation) so the load can be issued
+// unpredicated; callers substitute the pad code for d >= len afterwards.
+__device__ __forceinline__ int64_t slice_pos(int64_t p0, int len, bool reverse, int d)
+{
+    const int last = imax(len - 1, 0);
+    const int dc = imin(d, last);
+    return p0 + (reverse ? last - dc : dc);
 }
 
 // ---------------------------------------------------------------------------
@@ -500,15 +513,26 @@ __device__ __forceinline__ void load_tile(const SeqSetDev &rs, const SeqSetDev &
                                           int gl, uint8_t *ref_lds_g, uint8_t *q_lds_g,
                                           uint32_t (&qb)[C], int shift)
 {
+    // unpredicated loads (addresses clamped into the slice) so that all of them are in flight together
     uint32_t rbv[C];
+    if (raw) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            rbv[c] = fetch_base<true>(rs, slice_pos(rp0, R, reverse, gl * C + c));
+            qb[c] = fetch_base<true>(qs, slice_pos(qp0, Q, reverse, gl * C + c));
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            rbv[c] = fetch_base<false>(rs, slice_pos(rp0, R, reverse, gl * C + c));
+            qb[c] = fetch_base<false>(qs, slice_pos(qp0, Q, reverse, gl * C + c));
+        }
+    }
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const int d = gl * C + c;
-        uint32_t rv = kRefPad, qv = kQueryPad;
-        if (d < R) rv = fetch_base(rs, reverse ? rp0 + (R - 1 - d) : rp0 + d, raw);
-        if (d < Q) qv = fetch_base(qs, reverse ? qp0 + (Q - 1 - d) : qp0 + d, raw);
-        rbv[c] = rv;
-        qb[c] = qv;
+        rbv[c] = (d < R) ? rbv[c] : kRefPad;
+        qb[c] = (d < Q) ? qb[c] : kQueryPad;
     }
     // row r (1-based) of this tile lives at ref_lds_g[kGroup + shift + r - 1]; everything in front
     // (skew + start delay) and behind reads as the pad base

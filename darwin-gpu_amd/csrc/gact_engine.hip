@@ -61,6 +61,13 @@ struct SeqSet {
         d.use_raw = use_raw ? 1 : 0;
         return d;
     }
+    // The tile loaders issue their loads unpredicated (idle slots read position 0 of
+    // whichever set their stale state names), so a set that was never uploaded must
+    // still point at readable memory: it borrows another set's buffers.
+    gact::SeqSetDev dev_or(bool use_raw, const SeqSet &fallback) const
+    {
+        return d_raw ? dev(use_raw) : fallback.dev(use_raw);
+    }
     void release()
     {
         if (d_packed) (void)hipFree(d_packed);
@@ -195,7 +202,7 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
     const int blocks_needed = (waves_needed + 3) / 4;
     const int blocks = std::max(1, std::min(blocks_needed, e->grid_blocks));
     hipLaunchKernelGGL((gact::align_tiles_kernel<C>), dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream,
-                       e->kp, rs.dev(raw), qf.dev(raw), qr.dev(raw), sl.tiles.p, n, sl.results.p,
+                       e->kp, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.tiles.p, n, sl.results.p,
                        sl.states.p, states_stride, sl.d_ws);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -225,14 +232,14 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     const int seed_blocks = std::max(1, std::min((seed_waves + 3) / 4, e->grid_blocks));
     const int main_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->grid_blocks));
     hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
-                       e->kp, rs.dev(raw), qf.dev(raw), qr.dev(raw), sl.cands.p, first, n, rc_from, same_file,
+                       e->kp, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from, same_file,
                        sl.overlaps.p, queues(sl), e->p16 ? 1 : 0, sl.d_ws);
     HIP_TRY(hipGetLastError());
     sl.two_phase = e->p16;
     if (e->p16) {
         HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
         hipLaunchKernelGGL((gact::extend_p16_kernel<C>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
-                           sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev(raw), qr.dev(raw), same_file,
+                           sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file,
                            sl.overlaps.p, queues(sl), sl.d_ws);
         HIP_TRY(hipGetLastError());
     }
@@ -278,6 +285,7 @@ int run_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &qf, 
               const gact_tile *tiles, gact_tile_result *results, uint8_t *states, int32_t states_stride)
 {
     if (n == 0) return 0;
+    if (!rs.d_raw) return fail(GACT_HIP_EINVAL, "align_tiles: the reference read set has not been uploaded");
     if (sl.tiles.reserve(n) || sl.results.reserve(n) || sl.states.reserve((size_t)n * states_stride))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     HIP_TRY(hipMemcpyAsync(sl.tiles.p, tiles, (size_t)n * sizeof(gact_tile), hipMemcpyHostToDevice, sl.stream));
@@ -657,6 +665,10 @@ int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
     HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(gact::g_stamps), 8 * sizeof(unsigned long long)));
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_stamps), z, sizeof z));
+    unsigned long long y[8];
+    HIP_TRY(hipMemcpyFromSymbol(y, HIP_SYMBOL(gact::g_stamps2), sizeof y));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_stamps2), z, sizeof z));
+    if (y[3]) printf("  load_pair: fill %llu, loads %llu, lds-writes %llu clocks/iter\n", y[0] / y[3], y[1] / y[3], y[2] / y[3]);
     return 0;
 }
 #endif

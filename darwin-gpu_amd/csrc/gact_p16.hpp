@@ -13,6 +13,8 @@
 // done by the int32 kernel's seed launch (gact_kernels.hpp).
 #pragma once
 
+#include <type_traits>
+
 #include "gact_chain.hpp"
 
 namespace gact {
@@ -21,6 +23,7 @@ namespace gact {
 // summed over waves into g_stamps (never read by the kernel itself).
 #ifdef GACT_STAMPS
 __device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps2[8];
 #define GACT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #define GACT_ACC(slot, t0, t1) stamp_acc[slot] += (t1) - (t0)
 #else
@@ -274,26 +277,59 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 {
     using G = GeometryP16<C>;
     // pad the whole stream: rows in front of row 1 (skew + start delay) and behind row R
+    GACT_STAMP(l_a);
     uint32_t *ref32 = reinterpret_cast<uint32_t *>(ref8);
     for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = 0xffffffffu;
     wave_sync();
+    GACT_STAMP(l_b);
+    // all loads first (addresses clamped into the slice, never predicated, so they are all in
+    // flight together), pads substituted afterwards
+    uint32_t rv[kSlots][C], qv[kSlots][C];
+    auto issue = [&](auto raw_tag) {
+        constexpr bool RAW = decltype(raw_tag)::value;
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                rv[h][c] = fetch_base<RAW>(rs, slice_pos(pt.rp0[h], pt.R[h], pt.reverse[h], gl * C + c));
+                qv[h][c] = fetch_base<RAW>(qs, slice_pos(pt.qp0[h], pt.Q[h], pt.reverse[h], gl * C + c));
+            }
+        }
+    };
+    if (raw) issue(std::true_type{}); else issue(std::false_type{});
+#ifdef GACT_STAMPS
+    { uint32_t x = 0;
+#pragma unroll
+      for (int h = 0; h < kSlots; h++)
+#pragma unroll
+        for (int c = 0; c < C; c++) x ^= rv[h][c] ^ qv[h][c];
+      asm volatile("" :: "v"(x)); }
+#endif
+    GACT_STAMP(l_c);
 #pragma unroll
     for (int c = 0; c < C; c++) qb[c] = 0;
 #pragma unroll
     for (int h = 0; h < kSlots; h++) {
-        const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
         const int R = pt.R[h], Q = pt.Q[h];
         uint8_t *rrow = ref8 + (kGroup + pt.shift[h]) * 2 + h;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int d = gl * C + c;
-            uint32_t qv = kQueryPad;
-            if (d < R) rrow[d * 2] = (uint8_t)fetch_base(rs, pt.reverse[h] ? pt.rp0[h] + (R - 1 - d) : pt.rp0[h] + d, raw);
-            if (d < Q) qv = fetch_base(qs, pt.reverse[h] ? pt.qp0[h] + (Q - 1 - d) : pt.qp0[h] + d, raw);
-            q8[h * G::kTileMax + d] = (uint8_t)qv;
-            qb[c] |= qv << (16 * h);
+            const uint32_t qcode = (d < Q) ? qv[h][c] : kQueryPad;
+            if (d < R) rrow[d * 2] = (uint8_t)rv[h][c];
+            q8[h * G::kTileMax + d] = (uint8_t)qcode;
+            qb[c] |= qcode << (16 * h);
         }
     }
+#ifdef GACT_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GACT_STAMP(l_d);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_stamps2[0], l_b - l_a); atomicAdd(&g_stamps2[1], l_c - l_b); atomicAdd(&g_stamps2[2], l_d - l_c);
+        atomicAdd(&g_stamps2[3], 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------

@@ -160,6 +160,73 @@ struct ScoreWalk {
     }
 };
 
+// The chain kernels' walker: traceback (align.cpp:185-230) fused with the rescoring
+// of gact.cpp:197-210, written for few instructions per step -- every step of a
+// walker is a whole wave instruction however few lanes walk.  Lane / column /
+// stored-step of the current cell are tracked incrementally (no division), the
+// column bookkeeping is branch-free, pointer words come from the region cache.
+// rrow/qrow point at the LDS byte of DP row 1 / column 1; rstride is the ref
+// stream's byte stride.
+template <int C, int FMT>
+__device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int tB, int early,
+                                           const uint8_t *rrow, int rstride, const uint8_t *qrow, int phase,
+                                           const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
+                                           int &nst)
+{
+    int i = R, j = Q;
+    int l = (Q - 1) / C;
+    int c = (Q - 1) - l * C;
+    int k = R + l - tB;
+    int is = 0, js = 0, n = 0, since = 0;
+    int state = GACT_STATE_Z;
+    uint32_t nib = 0;
+    TbRegion<C> rg;
+    if (R >= 1 && Q >= 1 && early > 0) {
+        tb_refill_at<C>(ws, scratch, l, c, k, rg);
+        nib = tb_lookup_at<C, FMT>(scratch, l, c, k, rg);
+        state = nib & 3;
+    }
+    const bool left = phase == 0;
+    int score = wk.score, pend = wk.pend_gap, openf = wk.open_flag, havel = wk.have_left, lfg = wk.left_first_gap;
+    const uint8_t *ra = rrow + (R - 1) * rstride;
+    const uint8_t *qa = qrow + (Q - 1);
+    while (state != GACT_STATE_Z) {
+        // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209)
+        const int gap = state != GACT_STATE_M;
+        const int sub = (*ra == *qa) ? kp.match : kp.mismatch;
+        // left phase: the previously emitted column, if a gap, now learns its left neighbour;
+        // right phase: this column, if a gap, knows its left neighbour already
+        const int charge = left ? pend : gap;
+        const int nbr_gap = left ? gap : !openf;
+        score += charge ? (nbr_gap ? kp.ext : kp.open) : 0;
+        score += gap ? 0 : sub;
+        lfg = (left && !havel) ? gap : lfg;
+        havel = left ? 1 : havel;
+        pend = left ? gap : pend;
+        openf = left ? openf : !gap;
+        n++;
+        // ---- move (align.cpp:210-229)
+        const int isM = state == GACT_STATE_M, isI = state == GACT_STATE_I;
+        const int di = isM | isI, dj = isM | (state == GACT_STATE_D);
+        const int next = isM ? -1 : (isI ? ((nib & 8) ? GACT_STATE_M : GACT_STATE_I)
+                                         : ((nib & 4) ? GACT_STATE_M : GACT_STATE_D));
+        i -= di; j -= dj; is += di; js += dj;
+        ra -= di * rstride; qa -= dj;
+        c -= dj;
+        const int wrap = c < 0;
+        c += wrap ? C : 0; l -= wrap; k -= di + wrap;
+        if (is >= early || js >= early || i < 1 || j < 1) break;       // align.cpp:205, borders :101-107
+        if (++since == kTbSpan) {
+            tb_refill_at<C>(ws, scratch, l, c, k, rg);
+            since = 0;
+        }
+        nib = tb_lookup_at<C, FMT>(scratch, l, c, k, rg);
+        state = (next < 0) ? (int)(nib & 3) : next;
+    }
+    wk.score = score; wk.pend_gap = pend; wk.open_flag = openf; wk.have_left = havel; wk.left_first_gap = lfg;
+    ref_steps = is; query_steps = js; nst = n;
+}
+
 // after the traceback (gact.cpp:111-133 / :172-194); src = lane holding the walk's results
 __device__ __forceinline__ void chain_advance(ChainState &s, bool stop, const ScoreWalk &wk, int ref_steps,
                                               int query_steps, int nst, int src)
@@ -182,14 +249,30 @@ __device__ __forceinline__ void chain_advance(ChainState &s, bool stop, const Sc
     }
 }
 
-// device-side bookkeeping shared by the seed and the main launch
+// device-side bookkeeping shared by the seed and the main launch.  The seed launch
+// files every candidate it hands off under its estimated remaining chain length
+// (kBuckets classes of kBucketTiles tiles); the main launch pops the longest
+// class first, so the tail of the launch consists of short chains only.
+constexpr int kBuckets = 16;
+constexpr int kBucketTiles = 8;
 struct ChainQueues {
     int *pop_seed;               // next candidate index for the seed launch
-    int *live_count;             // candidates handed to the main launch
-    int *pop_main;               // next live index for the main launch
+    int *bucket_count;           // [kBuckets] candidates handed to the main launch, bucket 0 = longest
+    int *bucket_pop;             // [kBuckets] next index to pop per bucket
     unsigned long long *seed_cells;   // DP cells executed by the seed launch
-    int *live;                   // candidate ids handed off
+    int *live;                   // [kBuckets][live_stride] candidate ids handed off
+    int live_stride;
     ChainState *states;          // their chain states
 };
+
+// tiles this chain still has to run, roughly (each tile advances ~early bases)
+__device__ __forceinline__ int chain_bucket(const ChainState &s, const KParams &kp)
+{
+    int bases = imax(0, imin(s.ref_len - s.ref_pos, s.query_len - s.query_pos));
+    if (s.phase == 0) bases = imax(0, imin(s.ref_pos, s.query_pos)) +
+                              imax(0, imin(s.ref_len - s.rev_ref_pos, s.query_len - s.rev_query_pos));
+    const int tiles = bases / imax(kp.early, 1);
+    return imax(0, kBuckets - 1 - tiles / kBucketTiles);
+}
 
 }  // namespace gact

@@ -404,20 +404,19 @@ template <int C> struct TbRegion {
     int qbase0;          // first cached column quad of lane l0 (lane l0-1 always caches its last three)
 };
 
+// anchor cell given as (lane l0, column-in-lane c0, stored step k0 = i + l0 - tB)
 template <int C>
-__device__ __forceinline__ void tb_refill(const uint32_t *ws, uint32_t *scratch, int i, int j, int tB,
-                                          TbRegion<C> &rg)
+__device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
+                                             TbRegion<C> &rg)
 {
     constexpr int QN = C / 4;
-    const int l0 = (j - 1) / C;
-    const int c0 = (j - 1) - l0 * C;
     rg.l0 = l0;
     rg.qbase0 = imax(c0 - kTbSpan, 0) >> 2;
     const u32x4 *base = reinterpret_cast<const u32x4 *>(ws);
     const u32x4 *addr[12];
 #pragma unroll
     for (int sl = 0; sl < 2; sl++) {
-        const int k_anchor = i + (l0 - sl) - tB;
+        const int k_anchor = k0 - sl;
         const int fb = imax((k_anchor >> 3) - 1, 0);
         rg.fbase[sl] = fb;
         const int lane = imax(l0 - sl, 0);
@@ -451,11 +450,8 @@ __device__ __forceinline__ void tb_refill(const uint32_t *ws, uint32_t *scratch,
 // FMT 1: the packed kernel's word, low half 8 rows x 2 bits op code (0 ZERO 1 MATCH 2 INSERT 3 DELETE),
 //        high half 8 rows x 2 bits {ins_open<ins_extend, del_open<del_extend}.  Both return the FMT 0 nibble.
 template <int C, int FMT>
-__device__ __forceinline__ uint32_t tb_lookup(const uint32_t *scratch, int i, int j, int tB, const TbRegion<C> &rg)
+__device__ __forceinline__ uint32_t tb_lookup_at(const uint32_t *scratch, int l, int c, int k, const TbRegion<C> &rg)
 {
-    const int l = (j - 1) / C;
-    const int c = (j - 1) - l * C;
-    const int k = i + l - tB;
     const int sl = rg.l0 - l;                                   // 0 or 1
     const int lev = (k >> 3) - (sl ? rg.fbase[1] : rg.fbase[0]);
     const int qq = (c >> 2) - (sl ? C / 4 - 3 : rg.qbase0);
@@ -465,6 +461,19 @@ __device__ __forceinline__ uint32_t tb_lookup(const uint32_t *scratch, int i, in
     const uint32_t code = (w >> sh) & 3u, nfl = ~(w >> (sh + 16)) & 3u;
     const uint32_t state = code ? 4u - code : 0u;              // -> align.h:23 numbering Z0 D1 I2 M3
     return state | (nfl << 2);                                 // bit3 ins flag, bit2 del flag
+}
+
+template <int C>
+__device__ __forceinline__ void tb_refill(const uint32_t *ws, uint32_t *scratch, int i, int j, int tB, TbRegion<C> &rg)
+{
+    const int l0 = (j - 1) / C;
+    tb_refill_at<C>(ws, scratch, l0, (j - 1) - l0 * C, i + l0 - tB, rg);
+}
+template <int C, int FMT>
+__device__ __forceinline__ uint32_t tb_lookup(const uint32_t *scratch, int i, int j, int tB, const TbRegion<C> &rg)
+{
+    const int l = (j - 1) / C;
+    return tb_lookup_at<C, FMT>(scratch, l, (j - 1) - l * C, i + l - tB, rg);
 }
 
 // Same walk as traceback() above (align.cpp:185-230); `scratch` is this lane's

@@ -103,7 +103,7 @@ struct Slot {
     DevBuf<uint8_t> states;
     DevBuf<gact_candidate> cands;
     DevBuf<gact_overlap> overlaps;
-    int *d_counter = nullptr;            // 8 ints: pop_seed, live_count, pop_main, -, seed_cells(u64)
+    int *d_counter = nullptr;            // see queues()
     DevBuf<int> live;
     DevBuf<gact::ChainState> chain_states;
     uint32_t *d_ws = nullptr;
@@ -208,12 +208,20 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
     return 0;
 }
 
+// d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [8..8+kBuckets) bucket_count,
+// [8+kBuckets..8+2*kBuckets) bucket_pop
+constexpr int kCounterInts = 8 + 2 * gact::kBuckets;
+
 gact::ChainQueues queues(Slot &sl)
 {
     gact::ChainQueues q;
-    q.pop_seed = sl.d_counter; q.live_count = sl.d_counter + 1; q.pop_main = sl.d_counter + 2;
-    q.seed_cells = reinterpret_cast<unsigned long long *>(sl.d_counter + 4);
-    q.live = sl.live.p; q.states = sl.chain_states.p;
+    q.pop_seed = sl.d_counter;
+    q.seed_cells = reinterpret_cast<unsigned long long *>(sl.d_counter + 2);
+    q.bucket_count = sl.d_counter + 8;
+    q.bucket_pop = sl.d_counter + 8 + gact::kBuckets;
+    q.live = sl.live.p;
+    q.live_stride = (int)(sl.live.cap / gact::kBuckets);
+    q.states = sl.chain_states.p;
     return q;
 }
 
@@ -364,7 +372,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
             hipEventCreate(&sl.ev_mid) != hipSuccess ||
-            hipMalloc((void **)&sl.d_counter, 8 * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&sl.d_counter, kCounterInts * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&sl.d_flags, sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&sl.d_ws, e->ws_words_total * sizeof(uint32_t)) != hipSuccess) {
             gact_hip_destroy(e);
@@ -499,7 +507,7 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
         if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0 || c.query_pos > ql)
             return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
     }
-    if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve(n) || sl.chain_states.reserve(n))
+    if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve((size_t)n * gact::kBuckets) || sl.chain_states.reserve(n))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, cands, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
                                   sl.stream));
@@ -520,7 +528,7 @@ int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, i
     if (n > 0 && (e->sets[GACT_SET_REF].n == 0 || (need_f && e->sets[GACT_SET_QUERY].n == 0) ||
                   (need_r && e->sets[GACT_SET_QUERY_RC].n == 0)))
         return fail(GACT_HIP_EINVAL, "candidates_run: read sets not uploaded");
-    HIP_TRY(hipMemsetAsync(sl.d_counter, 0, 8 * sizeof(int), sl.stream));
+    HIP_TRY(hipMemsetAsync(sl.d_counter, 0, kCounterInts * sizeof(int), sl.stream));
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
     sl.two_phase = false;
     if (n > 0) {
@@ -605,10 +613,11 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
         HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));
-        int c[8];
+        int c[kCounterInts];
         HIP_TRY(hipMemcpy(c, sl.d_counter, sizeof c, hipMemcpyDeviceToHost));
-        st->handed_off = c[1];
-        memcpy(&st->seed_cells, &c[4], sizeof(int64_t));
+        st->handed_off = 0;
+        for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b];
+        memcpy(&st->seed_cells, &c[2], sizeof(int64_t));
     }
     return 0;
 }

@@ -236,8 +236,9 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
                 // first tile done: the rest of the chain belongs to the main launch
                 if (w.gl == 0) {
                     cq.states[s.cand] = s;
-                    const int slot = atomicAdd(cq.live_count, 1);
-                    cq.live[slot] = s.cand;
+                    const int b = chain_bucket(s, kp);
+                    const int slot = atomicAdd(&cq.bucket_count[b], 1);
+                    cq.live[(size_t)b * cq.live_stride + slot] = s.cand;
                     atomicAdd(cq.seed_cells, (unsigned long long)s.cells);
                 }
                 s.phase = 2;

@@ -354,12 +354,12 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
     uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
     uint32_t *wsB = wsA + kp.ws_words;
     const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
-    const int n_live = *cq.live_count;
 
     ChainState *st = chain_lds[group_in_block];
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
     wave_sync();
     bool exhausted = false;
+    int my_bucket = 0;           // longest chains first (ChainQueues)
     __builtin_amdgcn_s_setprio(3);
 #ifdef GACT_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -380,11 +380,19 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
             for (int guard = 0; guard < 3 && !pk.have; guard++) {
                 if (s.phase == 2) {
                     if (exhausted) break;
-                    int idx = 0;
-                    if (w.gl == 0) idx = atomicAdd(cq.pop_main, 1);
-                    idx = __shfl(idx, 0, kGroup);
-                    if (idx >= n_live) { exhausted = true; break; }
-                    s = cq.states[cq.live[idx]];
+                    int cand = -1;
+                    while (my_bucket < kBuckets) {
+                        int idx = 0;
+                        if (w.gl == 0) idx = atomicAdd(&cq.bucket_pop[my_bucket], 1);
+                        idx = __shfl(idx, 0, kGroup);
+                        if (idx < cq.bucket_count[my_bucket]) {
+                            cand = cq.live[(size_t)my_bucket * cq.live_stride + idx];
+                            break;
+                        }
+                        my_bucket++;
+                    }
+                    if (cand < 0) { exhausted = true; break; }
+                    s = cq.states[cand];
                 }
                 pk = chain_pick(s, kp, same_file, out, w.gl == 0);
             }
@@ -441,15 +449,9 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
                 const int sh = h ? pt.shift[1] : pt.shift[0];
                 const uint8_t *rrow = ref8 + (kGroup + sh) * 2 + h;
                 const uint8_t *qrow = q8 + h * G::kTileMax;
-                traceback_cached<C, 1>(h ? wsB : wsA, tb_lds[group_in_block][h], h ? pt.R[1] : pt.R[0],
-                                    h ? pt.Q[1] : pt.Q[0], tB - sh, kp.early, ref_steps, query_steps,
-                    [&](int state, int ci, int cj) {
-                        const bool gap = (state != GACT_STATE_M);
-                        int sub = 0;
-                        if (!gap) sub = (rrow[(ci - 1) * 2] == qrow[cj - 1]) ? kp.match : kp.mismatch;   // gact.cpp:207
-                        wk.column(phase, gap, sub, kp);
-                        nst++;
-                    });
+                walk_chain<C, 1>(h ? wsB : wsA, tb_lds[group_in_block][h], h ? pt.R[1] : pt.R[0],
+                                 h ? pt.Q[1] : pt.Q[0], tB - sh, kp.early, rrow, 2, qrow, phase, kp, wk, ref_steps,
+                                 query_steps, nst);
             }
         }
         GACT_STAMP(t_f);

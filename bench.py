@@ -152,13 +152,17 @@ def main():
         measured_rate = eng.measure_valu_rate()
         peak_tops = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
         roofline = {
+            # integer-VALU roofline: algorithmic work = 24 int32 ops per DP cell
+            # against the int32 issue rate.  The main kernel runs its score recurrence as packed int16
+            # (two cells per lane-op), so it can exceed 1.0 on this scale; frac_packed16 prices the same
+            # work against the packed issue rate (2 x).
             "bound": "valu", "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 3),
-            "unit": "TOP/s (int32 lane-ops, 24 per DP cell)", "frac": round(achieved_tops / peak_tops, 4),
+            "unit": "TOP/s (int32-equivalent lane-ops, 24 per DP cell)", "frac": round(achieved_tops / peak_tops, 4),
+            "frac_packed16": round(achieved_tops / (2 * peak_tops), 4),
             "traffic": None,
             "kernel": "extend_p16_kernel" if packed else "extend_kernel", "kernel_ms": round(float(k_ms), 3),
             "kernel_cells": main_cells, "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
             "measured_valu_peak_tops": round(measured_rate / 1e12, 3),
-            "frac_of_measured_peak": round(achieved_tops / (measured_rate / 1e12), 4),
             "peak_gcups": round(peak_tops * 1e3 / OPS_PER_CELL, 1),
             "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
             "waves_per_cu": info["waves_per_cu"],
@@ -168,7 +172,7 @@ def main():
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(max_dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
+            "dtype": "int16x2 (packed) main kernel, int32 seed kernel" if packed else "int32", "data": "synthetic",
             "config": {"workload": args.workload + "_self_overlap", "tile_size": 320, "tile_overlap": 120,
                        "scoring": "+1/-1/-1/-1", "reads": len(reads), "bases": int(offs[-1]),
                        "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles,

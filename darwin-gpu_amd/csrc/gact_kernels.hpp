@@ -146,6 +146,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
 {
     using G = Geometry<C>;
     __shared__ uint8_t lds[(kBlockThreads / 64) * kGroupsPerWave * G::kGroupLds];
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[(kBlockThreads / 64) * kGroupsPerWave][kTbScratchWords];
 
     const WaveCtx w = wave_ctx();
     const int wave_in_block = threadIdx.x >> 6;
@@ -216,21 +217,10 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
             int ref_steps = 0, query_steps = 0, nst = 0;
             ScoreWalk wk;
             wk.load(s);
-            if (!stop && w.gl == 0) {
-                const int phase = s.phase;
-                traceback<C>(ws, i0, j0, po.tB, kp.early, ref_steps, query_steps,
-                    [&](int state, int ci, int cj) {
-                        const bool gap = (state != GACT_STATE_M);
-                        int sub = 0;
-                        if (!gap) {
-                            const uint32_t rbv = ref_lds_g[kGroup + gt.shift + ci - 1];
-                            const uint32_t qbv = q_lds_g[cj - 1];
-                            sub = (rbv == qbv) ? kp.match : kp.mismatch;     // gact.cpp:207
-                        }
-                        wk.column(phase, gap, sub, kp);
-                        nst++;
-                    });
-            }
+            if (!stop && w.gl == 0)
+                walk_chain<C, 0>(ws, tb_lds[wave_in_block * kGroupsPerWave + w.g], i0, j0, po.tB, kp.early,
+                                 ref_lds_g + kGroup + gt.shift, 1, q_lds_g, s.phase, kp, wk, ref_steps, query_steps,
+                                 nst);
             chain_advance(s, stop, wk, ref_steps, query_steps, nst, 0);
             if (seed_mode && !s.first_tile) {
                 // first tile done: the rest of the chain belongs to the main launch

@@ -66,7 +66,8 @@ def build(force=False, verbose=False):
 
 
 DRIVER_PATH = os.path.join(_PKG, "host", "darwin_hip")
-DRIVER_SOURCES = [os.path.join(_PKG, "host", f) for f in ("darwin_hip.cpp", "gact_shim.cpp", "gact.h", "align.h")]
+DRIVER_SOURCES = [os.path.join(_PKG, "host", f) for f in
+                  ("darwin_hip.cpp", "gact_shim.cpp", "dsoft.cpp", "gact.h", "align.h", "dsoft.h")]
 
 
 def build_driver(force=False, verbose=False):
@@ -77,7 +78,7 @@ def build_driver(force=False, verbose=False):
         if os.path.getmtime(DRIVER_PATH) >= newest:
             return DRIVER_PATH
     cmd = ["g++", "-O2", "-std=c++14", "-pthread", "-I" + os.path.join(_ROOT, "include"),
-           "-I" + os.path.join(_PKG, "host"), "-o", DRIVER_PATH, DRIVER_SOURCES[0], DRIVER_SOURCES[1],
+           "-I" + os.path.join(_PKG, "host"), "-o", DRIVER_PATH, DRIVER_SOURCES[0], DRIVER_SOURCES[1], DRIVER_SOURCES[2],
            "-L" + _PKG, "-lgact_hip", "-Wl,-rpath," + _PKG]
     if verbose:
         print(" ".join(cmd))

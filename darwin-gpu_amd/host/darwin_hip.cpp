@@ -1,6 +1,7 @@
 // darwin_hip.cpp -- a darwin.cpp-shaped driver around the GACT shim.
 //
-//   darwin_hip <REF.fasta> <READS.fasta> CPU_THREADS --candidates FILE [--params params.cfg]
+//   darwin_hip <REF.fasta> <READS.fasta> CPU_THREADS [--params params.cfg]
+//              [--candidates FILE | --dump-candidates FILE [--dsoft-only]]
 //
 // Plays the part of reference darwin.cpp:451-646 for the GACT stage: owns the
 // globals gact.cpp reads, loads params.cfg and the two FASTA files, builds the
@@ -9,8 +10,10 @@
 // GACT_Batch for its forward and then its reverse-complement calls
 // (darwin.cpp:429-433) into darwin.<thread>.out, GPU_close.
 //
-// The D-SOFT filter is outside this path: candidates come
-// from FILE, int32 records {ref_id, query_id, ref_pos, query_pos, comp}.
+// Candidates come from the D-SOFT restatement (dsoft.cpp; darwin.cpp:209-288 per read:
+// forward strand, then reverse complement) or, with --candidates, from FILE: int32
+// records {ref_id, query_id, ref_pos, query_pos, comp}.  --dump-candidates writes the
+// same format; --dsoft-only stops after the filter (no GPU is touched).
 //
 //   darwin_hip --selftest FILE   exercises AlignWithBT / Align_Batch_GPU / GACT
 //                                on the cases in FILE and prints what they return.
@@ -27,6 +30,7 @@
 #include <vector>
 
 #include "align.h"
+#include "dsoft.h"
 #include "gact.h"
 
 // ---- the globals of darwin.cpp:39-93 that gact.cpp / the shim read
@@ -207,10 +211,13 @@ int main(int argc, char *argv[])
                         "[--params params.cfg]\n");
         return 1;
     }
-    std::string cand_path, cfg_path = "params.cfg";
-    for (int a = 4; a + 1 < argc; a += 2) {
-        if (!strcmp(argv[a], "--candidates")) cand_path = argv[a + 1];
-        else if (!strcmp(argv[a], "--params")) cfg_path = argv[a + 1];
+    std::string cand_path, dump_path, cfg_path = "params.cfg";
+    bool dsoft_only = false;
+    for (int a = 4; a < argc; a++) {
+        if (!strcmp(argv[a], "--candidates") && a + 1 < argc) cand_path = argv[++a];
+        else if (!strcmp(argv[a], "--dump-candidates") && a + 1 < argc) dump_path = argv[++a];
+        else if (!strcmp(argv[a], "--params") && a + 1 < argc) cfg_path = argv[++a];
+        else if (!strcmp(argv[a], "--dsoft-only")) dsoft_only = true;
     }
     std::map<std::string, double> cfg = parse_cfg(cfg_path);
     auto get = [&](const char *k, int dflt) { return cfg.count(k) ? (int)cfg[k] : dflt; };
@@ -218,37 +225,76 @@ int main(int argc, char *argv[])
     gap_open = get("GACT_scoring/gap_open", -1); gap_extend = get("GACT_scoring/gap_extend", -1);
     first_tile_score_threshold = get("GACT_first_tile/first_tile_score_threshold", 35);
     tile_size = get("GACT_extend/tile_size", 320); tile_overlap = get("GACT_extend/tile_overlap", 120);
+    DsoftParams dp;
+    dp.seed_size = get("DSOFT_params/seed_size", 14); dp.bin_size = (uint32_t)get("DSOFT_params/bin_size", 64);
+    dp.window_size = (uint32_t)get("DSOFT_params/window_size", 4); dp.threshold = get("DSOFT_params/threshold", 21);
+    dp.num_seeds = get("DSOFT_params/num_seeds", 800);
+    dp.seed_occurence_multiple = (uint32_t)get("DSOFT_params/seed_occurence_multiple", 32);
+    dp.max_candidates = get("DSOFT_params/max_candidates", 1000000);
     num_threads = std::stoi(argv[3]);
+    if (num_threads < 1) num_threads = 1;
     const std::string ref_path(argv[1]), reads_path(argv[2]);
     same_file = (ref_path == reads_path);                         // darwin.cpp:500-502
     printf("same_file: %d\n", same_file);
     printf("Scores: match = %d, mismatch = %d, gap_open = %d, gap_extend = %d\n", match_score, mismatch_score,
            gap_open, gap_extend);
 
-    std::vector<long long int> dummy;
     parse_fasta(ref_path, reference_descrips, reference_seqs, reference_lengths);
     parse_fasta(reads_path, reads_descrips, reads_seqs, reads_lengths);
     for (const std::string &r : reads_seqs) rev_reads_seqs.push_back(rev_comp(r));
     std::cout << "Number of reads: " << reads_seqs.size() << std::endl;
 
-    std::vector<Cand> cands;
-    {
+    // per-thread candidate lists, contiguous read ranges like darwin.cpp:619-629
+    std::vector<std::vector<Cand> > per_thread(num_threads);
+    if (!cand_path.empty()) {
+        std::vector<Cand> cands;
         std::ifstream in(cand_path, std::ios::binary);
         if (!in) { fprintf(stderr, "cannot open candidates file '%s'\n", cand_path.c_str()); return 1; }
         Cand c;
         while (in.read((char *)&c, sizeof c)) cands.push_back(c);
+        const size_t per = (cands.size() + num_threads - 1) / num_threads;
+        for (int i = 0; i < num_threads; i++) {
+            const size_t lo = std::min(cands.size(), i * per), hi = std::min(cands.size(), lo + per);
+            per_thread[i].assign(cands.begin() + lo, cands.begin() + hi);
+        }
+    } else {
+        DsoftIndex index;
+        index.build(reference_seqs, dp);
+        printf("Reference length: %u, %zu pieces\n", index.reference_length(), reference_seqs.size());
+        const int num_reads = (int)reads_seqs.size();
+        const int reads_per_thread = (int)std::ceil(1.0 * num_reads / num_threads);
+        std::vector<std::thread> filt;
+        for (int i = 0; i < num_threads; i++) {
+            filt.push_back(std::thread([&, i] {
+                const int lo = std::min(num_reads, i * reads_per_thread), hi = std::min(num_reads, lo + reads_per_thread);
+                DsoftScratch sc;
+                std::vector<DsoftCandidate> f, r;
+                for (int k = lo; k < hi; k++) {
+                    f.clear(); r.clear();
+                    index.query(reads_seqs[k].data(), (uint32_t)reads_seqs[k].size(), k, sc, f);        // darwin.cpp:213
+                    index.query(rev_reads_seqs[k].data(), (uint32_t)rev_reads_seqs[k].size(), k, sc, r);  // :252
+                    for (const DsoftCandidate &c : f) per_thread[i].push_back(Cand{c.ref_id, c.query_id, c.ref_pos, c.query_pos, 0});
+                    for (const DsoftCandidate &c : r) per_thread[i].push_back(Cand{c.ref_id, c.query_id, c.ref_pos, c.query_pos, 1});
+                }
+            }));
+        }
+        for (auto &t : filt) t.join();
     }
-    printf("num_candidates: %zu\n", cands.size());
+    size_t total = 0;
+    for (auto &v : per_thread) total += v.size();
+    printf("num_candidates: %zu\n", total);
+    if (!dump_path.empty()) {
+        std::ofstream out(dump_path, std::ios::binary);
+        for (auto &v : per_thread) out.write((const char *)v.data(), (std::streamsize)(v.size() * sizeof(Cand)));
+    }
+    if (dsoft_only) return 0;
 
     std::vector<GPU_storage> s;
     GPU_init(tile_size, tile_overlap, gap_open, gap_extend, match_score, mismatch_score, tile_size - tile_overlap,
              &s, num_threads);
     std::vector<std::thread> threads;
-    const size_t per = (cands.size() + num_threads - 1) / (num_threads > 0 ? num_threads : 1);
-    for (int i = 0; i < num_threads; i++) {
-        const size_t lo = std::min(cands.size(), i * per), hi = std::min(cands.size(), lo + per);
-        threads.push_back(std::thread(feeder, i, &cands, lo, hi, s[i]));
-    }
+    for (int i = 0; i < num_threads; i++)
+        threads.push_back(std::thread(feeder, i, &per_thread[i], (size_t)0, per_thread[i].size(), s[i]));
     for (auto &t : threads) t.join();
     GPU_close(&s, num_threads);
     return 0;

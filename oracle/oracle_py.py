@@ -159,6 +159,47 @@ class RefLib:
             C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
             C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
 
+    def dsoft_candidates(self, reference_seqs, queries, seed_size=14, bin_size=64, window_size=4, threshold=21,
+                         num_seeds=800, seed_occurence_multiple=32, max_candidates=1000000):
+        """SeedPosTable + DSOFT of the reference on (reference_seqs, queries); returns per query the decoded
+        candidates [(ref_id, ref_pos, query_pos)] exactly as darwin.cpp:213-224 derives them."""
+        L = self.lib
+        L.ref_dsoft_build.restype = C.c_void_p
+        L.ref_dsoft_build.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.ref_dsoft_query.restype = C.c_int
+        L.ref_dsoft_query.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_uint32]
+        # darwin.cpp:532-543: pad every sequence with 'N' to whole bins
+        concat, start_bin, bin_to_chr, cur = b"", [], [], 0
+        for i, r in enumerate(reference_seqs):
+            r = _b(r)
+            start_bin.append(cur)
+            concat += r
+            nb = len(r) // bin_size
+            bin_to_chr += [i] * nb
+            cur += nb
+            if len(r) % bin_size:
+                concat += b"N" * (bin_size - len(r) % bin_size)
+                bin_to_chr.append(i)
+                cur += 1
+        num_bins = 1 + (len(concat) >> (bin_size.bit_length() - 1))
+        tab = L.ref_dsoft_build(concat + b"\0" * 64, len(concat), seed_size, seed_occurence_multiple, bin_size,
+                                window_size)
+        out = (C.c_uint64 * max_candidates)()
+        res = []
+        for q in queries:
+            q = _b(q)
+            n = L.ref_dsoft_query(tab, q + b"\0" * 64, len(q), num_seeds, threshold, out, max_candidates, num_bins)
+            cands = []
+            for k in range(n):
+                ref_pos = out[k] >> 32
+                chr_id = bin_to_chr[ref_pos // bin_size] if ref_pos // bin_size < len(bin_to_chr) else 0
+                ref_pos -= start_bin[chr_id] * bin_size
+                ref_pos = min(ref_pos, len(reference_seqs[chr_id]))
+                cands.append((chr_id, int(ref_pos), int(out[k] & 0xffffffff)))
+            res.append(cands)
+        return res
+
     def align_with_bt(self, ref, query, scoring=(1, -1, -1, -1), reverse=False, first=False,
                       early_terminate=200, ref_pos=None, query_pos=None):
         ref, query = _b(ref), _b(query)

@@ -9,7 +9,10 @@
  * gact.h:30-32; defined in darwin.cpp:39,65-69,82-93) and calls
  * AlignWithBT / GACT with the caller's arguments.
  *
- * Used to (1) validate oracle/gact_oracle.c, (2) generate tests/golden/.
+ * Used to (1) validate oracle/gact_oracle.c, (2) generate tests/golden/,
+ * (3) pin the D-SOFT restatement (darwin-gpu_amd/host/dsoft.cpp) against the
+ *     reference's own SeedPosTable (seed_pos_table.cpp + ntcoding.cpp, also
+ *     compiled unchanged).
  */
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +26,7 @@
 
 #include "align.h"   /* from /root/reference via -I */
 #include "gact.h"
+#include "seed_pos_table.h"
 
 /* globals darwin.cpp defines for gact.cpp */
 bool same_file = false;
@@ -96,6 +100,25 @@ int ref_gact(const char *ref_str, const char *query_str, int ref_length, int que
     if ((int)s.size() + 1 > line_cap) return -1;
     memcpy(line_out, s.c_str(), s.size() + 1);
     return (int)s.size();
+}
+
+/* SeedPosTable (seed_pos_table.cpp:46-98) over an already concatenated + padded reference */
+void *ref_dsoft_build(const char *ref_concat, uint32_t ref_length, int kmer_size, uint32_t seed_occurence_multiple,
+                      uint32_t bin_size, uint32_t window_size)
+{
+    return new SeedPosTable((char *)ref_concat, ref_length, kmer_size, seed_occurence_multiple, bin_size,
+                            window_size);
+}
+
+/* SeedPosTable::DSOFT (seed_pos_table.cpp:100-167); raw (hit << 32 | offset) words into out[] */
+int ref_dsoft_query(void *table, const char *query, uint32_t query_length, int num_seeds, int threshold,
+                    uint64_t *out, int max_candidates, uint32_t num_bins)
+{
+    static std::vector<uint64_t> bin_count;
+    static std::vector<uint32_t> nz(25000000);     /* the reference's own bound (seed_pos_table.h:33) */
+    if (bin_count.size() != num_bins) bin_count.assign(num_bins, 0);
+    return ((SeedPosTable *)table)->DSOFT((char *)query, query_length, num_seeds, threshold, out, bin_count.data(),
+                                          nz.data(), max_candidates);
 }
 
 } /* extern "C" */

@@ -103,3 +103,26 @@ def test_driver_end_to_end(oracle, tmp_path, threads):
     assert sorted(set(got)) == sorted(set(want))
     assert sorted(got) == sorted(want)
     assert len(want) > 50
+
+
+def test_end_to_end_from_fasta_equals_reference_program(tmp_path):
+    """FASTA -> D-SOFT restatement -> HIP GACT -> darwin.<t>.out, compared with the lines the REFERENCE's own
+    CPU program (oracle/_ref/darwin_cpu) printed for the same FASTA and params.cfg (tests/golden/e2e.json):
+    the reference's regression method, x_scalingrun.sh:5-22."""
+    import json
+    import os
+    from test_dsoft import CFG
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fasta = json.load(open(os.path.join(gold, "dsoft.json")))["fasta"]
+    e2e = json.load(open(os.path.join(gold, "e2e.json")))
+    (tmp_path / "reads.fasta").write_text(fasta)
+    (tmp_path / "params.cfg").write_text(CFG % e2e["seed_size"])
+    for threads in (1, 3):
+        out = subprocess.run([_driver(), "reads.fasta", "reads.fasta", str(threads)], capture_output=True, text=True,
+                             cwd=tmp_path, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        got = []
+        for t in range(threads):
+            got += open(tmp_path / ("darwin.%d.out" % t)).read().splitlines()
+        assert sorted(got) == e2e["lines_sorted"]
+        assert len(got) > 40

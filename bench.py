@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ecoli10x")
+    ap.add_argument("--candidates", default="dsoft", choices=["dsoft", "synthetic"],
+                    help="dsoft: candidates from the D-SOFT filter itself; synthetic: placed from simulator truth")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even at N=1")
@@ -74,7 +76,7 @@ def main():
 
     # ---- workload: one genome block per rank, read sets replicated everywhere
     t_gen = time.time()
-    blk = workload.make_block(args.workload, block=rank)
+    blk = workload.make_block(args.workload, block=rank, candidates=args.candidates)
     blocks = gdist.exchange_blocks(dist, (blk.rs.reads, blk.cf, blk.cr), world)
     reads, cf_all, cr_all = gdist.merge_blocks(blocks)
     my_cf = gdist.deal(cf_all, rank, world)
@@ -173,7 +175,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(max_dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16x2 (packed) main kernel, int32 seed kernel" if packed else "int32", "data": "synthetic",
-            "config": {"workload": args.workload + "_self_overlap", "tile_size": 320, "tile_overlap": 120,
+            "config": {"workload": args.workload + "_self_overlap", "candidate_source": args.candidates, "tile_size": 320, "tile_overlap": 120,
                        "scoring": "+1/-1/-1/-1", "reads": len(reads), "bases": int(offs[-1]),
                        "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles,
                        "cells_per_step": tot_cells, "parallelism": "candidates dealt round-robin over %d GPU(s)" % world,

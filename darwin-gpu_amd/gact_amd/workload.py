@@ -6,9 +6,38 @@ candidates only pair reads of that block.  One block of `ecoli10x` is config
 1/2; the 8-GPU run uses one block per rank so per-GPU work is fixed (weak
 scaling) while every rank still holds the whole replicated read set.
 """
+import os
+import subprocess
+import tempfile
+
 import numpy as np
 
 from . import synth
+
+PARAMS_CFG = """[GACT_scoring]
+match = 1
+mismatch = -1
+gap_open = -1
+gap_extend = -1
+
+[DSOFT_params]
+seed_size  = 14
+bin_size   = 64
+window_size= 4
+threshold  = 21
+num_seeds  = 800
+seed_occurence_multiple = 32
+max_candidates = 1000000
+num_nz_bins    = 2500000
+
+[GACT_first_tile]
+first_tile_size = 128
+first_tile_score_threshold = 35
+
+[GACT_extend]
+tile_size = 320
+tile_overlap = 120
+"""   # the reference's params.cfg values (params.cfg:1-23)
 
 CONFIGS = {
     # 10x E.coli-shape PBSIM reads, self-overlap (configs[0]/[1])
@@ -29,11 +58,38 @@ class Block:
         self.rs, self.cf, self.cr = rs, cf, cr
 
 
-def make_block(name, block=0):
+def dsoft_candidates(rs, threads=None):
+    """Candidates of the D-SOFT filter itself (host/dsoft.cpp through the driver's --dsoft-only mode,
+    reference parameters) for the self-overlap run of a read set: (forward, reverse-complement) arrays
+    in the order darwin.cpp:209-288 produces them."""
+    from . import engine
+    drv = engine.build_driver()
+    threads = threads or min(16, os.cpu_count() or 1)
+    with tempfile.TemporaryDirectory() as d:
+        rs.write_fasta(os.path.join(d, "reads.fasta"))
+        with open(os.path.join(d, "params.cfg"), "w") as f:
+            f.write(PARAMS_CFG)
+        subprocess.check_call([drv, "reads.fasta", "reads.fasta", str(threads), "--dsoft-only",
+                               "--dump-candidates", "cands.bin"], cwd=d, stdout=subprocess.DEVNULL)
+        raw = np.fromfile(os.path.join(d, "cands.bin"), dtype=np.int32).reshape(-1, 5)
+    out = []
+    for comp in (0, 1):
+        sel = raw[raw[:, 4] == comp]
+        c = np.zeros(len(sel), dtype=synth.CAND_DTYPE)
+        c["ref_id"], c["query_id"], c["ref_pos"], c["query_pos"] = sel[:, 0], sel[:, 1], sel[:, 2], sel[:, 3]
+        out.append(c)
+    return out[0], out[1]
+
+
+def make_block(name, block=0, candidates="dsoft"):
+    """candidates: "dsoft" = run the filter (needs the built driver), "synthetic" = place hits from simulator truth"""
     cfg = dict(CONFIGS[name])
     seed = cfg.pop("seed") + 1000 * block
     rs = synth.simulate_reads(seed=seed, **cfg)
-    cf, cr = synth.synth_candidates(rs, seed=seed + 1)
+    if candidates == "dsoft":
+        cf, cr = dsoft_candidates(rs)
+    else:
+        cf, cr = synth.synth_candidates(rs, seed=seed + 1)
     return Block(rs, cf, cr)
 
 

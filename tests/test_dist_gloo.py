@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gact_amd import dist as gdist, synth, workload
     import oracle_py
-    blk = workload.make_block("tiny", block=rank)
+    blk = workload.make_block("tiny", block=rank, candidates="synthetic")
     blocks = gdist.exchange_blocks(dist, (blk.rs.reads, blk.cf, blk.cr), world)
     reads, cf_all, cr_all = gdist.merge_blocks(blocks)
     offs = np.zeros(len(reads) + 1, dtype=np.int64)

@@ -86,6 +86,14 @@ def build_driver(force=False, verbose=False):
     return DRIVER_PATH
 
 
+def driver_path():
+    """the built driver; compiled here only if it does not exist yet (never re-built behind the back of
+    concurrently running ranks -- __graft_entry__.build() is what refreshes stale binaries)"""
+    if os.path.exists(DRIVER_PATH) and os.path.exists(LIB_PATH):
+        return DRIVER_PATH
+    return build_driver()
+
+
 _lib = None
 
 

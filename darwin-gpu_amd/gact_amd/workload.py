@@ -63,7 +63,7 @@ def dsoft_candidates(rs, threads=None):
     reference parameters) for the self-overlap run of a read set: (forward, reverse-complement) arrays
     in the order darwin.cpp:209-288 produces them."""
     from . import engine
-    drv = engine.build_driver()
+    drv = engine.driver_path()
     threads = threads or min(16, os.cpu_count() or 1)
     with tempfile.TemporaryDirectory() as d:
         rs.write_fasta(os.path.join(d, "reads.fasta"))

@@ -167,23 +167,22 @@ struct ScoreWalk {
 // column bookkeeping is branch-free, pointer words come from the region cache.
 // rrow/qrow point at the LDS byte of DP row 1 / column 1; rstride is the ref
 // stream's byte stride.
-template <int C, int FMT>
-__device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int tB, int early,
-                                           const uint8_t *rrow, int rstride, const uint8_t *qrow, int phase,
-                                           const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
-                                           int &nst)
+// (l, c, k) = lane, column-in-lane and stored step of the start cell (R, Q) in the pass's layout;
+// CW columns per lane, QN column quads stored per lane.
+template <int CW, int FMT, int QN = CW / 4>
+__device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l, int c, int k,
+                                           int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
+                                           int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
+                                           int &query_steps, int &nst)
 {
     int i = R, j = Q;
-    int l = (Q - 1) / C;
-    int c = (Q - 1) - l * C;
-    int k = R + l - tB;
     int is = 0, js = 0, n = 0, since = 0;
     int state = GACT_STATE_Z;
     uint32_t nib = 0;
-    TbRegion<C> rg;
+    TbRegion<CW> rg;
     if (R >= 1 && Q >= 1 && early > 0) {
-        tb_refill_at<C>(ws, scratch, l, c, k, rg);
-        nib = tb_lookup_at<C, FMT>(scratch, l, c, k, rg);
+        tb_refill_at<CW, QN>(ws, scratch, l, c, k, rg);
+        nib = tb_lookup_at<CW, FMT, QN>(scratch, l, c, k, rg);
         state = nib & 3;
     }
     const bool left = phase == 0;
@@ -214,13 +213,13 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         ra -= di * rstride; qa -= dj;
         c -= dj;
         const int wrap = c < 0;
-        c += wrap ? C : 0; l -= wrap; k -= di + wrap;
+        c += wrap ? CW : 0; l -= wrap; k -= di + wrap;
         if (is >= early || js >= early || i < 1 || j < 1) break;       // align.cpp:205, borders :101-107
         if (++since == kTbSpan) {
-            tb_refill_at<C>(ws, scratch, l, c, k, rg);
+            tb_refill_at<CW, QN>(ws, scratch, l, c, k, rg);
             since = 0;
         }
-        nib = tb_lookup_at<C, FMT>(scratch, l, c, k, rg);
+        nib = tb_lookup_at<CW, FMT, QN>(scratch, l, c, k, rg);
         state = (next < 0) ? (int)(nib & 3) : next;
     }
     wk.score = score; wk.pend_gap = pend; wk.open_flag = openf; wk.have_left = havel; wk.left_first_gap = lfg;

@@ -398,18 +398,18 @@ __device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int 
 constexpr int kTbSpan = 8;
 constexpr int kTbScratchWords = 12 * 4;      // dwords of LDS per walker
 
-template <int C> struct TbRegion {
+template <int CW> struct TbRegion {
     int l0;              // lane of the anchor column
     int fbase[2];        // first cached flush block, for lane l0 and lane l0-1
     int qbase0;          // first cached column quad of lane l0 (lane l0-1 always caches its last three)
 };
 
 // anchor cell given as (lane l0, column-in-lane c0, stored step k0 = i + l0 - tB)
-template <int C>
+// CW = columns per lane, QN = 16-byte column quads stored per lane and flush block
+template <int CW, int QN = CW / 4>
 __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
-                                             TbRegion<C> &rg)
+                                             TbRegion<CW> &rg)
 {
-    constexpr int QN = C / 4;
     rg.l0 = l0;
     rg.qbase0 = imax(c0 - kTbSpan, 0) >> 2;
     const u32x4 *base = reinterpret_cast<const u32x4 *>(ws);
@@ -449,12 +449,12 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
 // FMT 0: the int32 kernels' word, 8 rows x 4 bits {ins_open>=ins_extend, del_open>=del_extend, op}.
 // FMT 1: the packed kernel's word, low half 8 rows x 2 bits op code (0 ZERO 1 MATCH 2 INSERT 3 DELETE),
 //        high half 8 rows x 2 bits {ins_open<ins_extend, del_open<del_extend}.  Both return the FMT 0 nibble.
-template <int C, int FMT>
-__device__ __forceinline__ uint32_t tb_lookup_at(const uint32_t *scratch, int l, int c, int k, const TbRegion<C> &rg)
+template <int CW, int FMT, int QN = CW / 4>
+__device__ __forceinline__ uint32_t tb_lookup_at(const uint32_t *scratch, int l, int c, int k, const TbRegion<CW> &rg)
 {
     const int sl = rg.l0 - l;                                   // 0 or 1
     const int lev = (k >> 3) - (sl ? rg.fbase[1] : rg.fbase[0]);
-    const int qq = (c >> 2) - (sl ? C / 4 - 3 : rg.qbase0);
+    const int qq = (c >> 2) - (sl ? QN - 3 : rg.qbase0);
     const uint32_t w = scratch[(((sl * 2 + lev) * 3 + qq) << 2) + (c & 3)];
     if (FMT == 0) return (w >> (28 - 4 * (k & 7))) & 15u;
     const int sh = 14 - 2 * (k & 7);

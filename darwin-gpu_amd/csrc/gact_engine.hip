@@ -20,6 +20,7 @@
 #include "gact_hip.h"
 #include "gact_kernels.hpp"
 #include "gact_p16.hpp"
+#include "gact_p16s.hpp"
 
 namespace {
 
@@ -118,6 +119,7 @@ struct gact_hip_engine {
     gact::KParams kp;
     int C = 20;                 // columns per lane
     bool p16 = false;           // scoring fits the packed-int16 main kernel
+    bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
     gact::P16Consts kc;
     hipDeviceProp_t prop;
     int grid_blocks = 0;        // persistent grid
@@ -246,9 +248,14 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     sl.two_phase = e->p16;
     if (e->p16) {
         HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
-        hipLaunchKernelGGL((gact::extend_p16_kernel<C>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
-                           sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file,
-                           sl.overlaps.p, queues(sl), sl.d_ws);
+        if (e->split)
+            hipLaunchKernelGGL((gact::extend_p16s_kernel<7, 13>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
+                               sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
+                               same_file, sl.overlaps.p, queues(sl), sl.d_ws);
+        else
+            hipLaunchKernelGGL((gact::extend_p16_kernel<C>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
+                               sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
+                               same_file, sl.overlaps.p, queues(sl), sl.d_ws);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -261,7 +268,9 @@ template <int C> int occupancy_blocks(int *out)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
     int c = a;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::extend_p16_kernel<C>, gact::kBlockThreads, 0));
-    *out = std::max(1, std::min(std::min(a, b), c));
+    int d = c;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, gact::extend_p16s_kernel<7, 13>, gact::kBlockThreads, 0));
+    *out = std::max(1, std::min(std::min(a, b), std::min(c, d)));
     return 0;
 }
 
@@ -357,6 +366,9 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->kp.ws_words = (e->C == 20) ? gact::Geometry<20>::kWsWords : gact::Geometry<32>::kWsWords;
     e->p16 = gact::p16_scoring_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
              getenv("GACT_HIP_FORCE_INT32") == nullptr;
+    e->split = e->p16 && e->C == 20 && e->kp.early <= gact::GeometrySplit<7, 13>::W2 &&
+               getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
+    static_assert(gact::GeometrySplit<7, 13>::kWsWords <= gact::Geometry<20>::kWsWords, "workspace too small");
     e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);
     e->kc.open = gact::pk2(p->gap_open); e->kc.ext = gact::pk2(p->gap_extend);
     e->kc.ninf = gact::pk2(gact::kNegInf16); e->kc.one = gact::pk2(1);
@@ -609,7 +621,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
     st->main_ms = st->total_ms;
-    st->packed16 = sl.two_phase ? 1 : 0;
+    st->packed16 = sl.two_phase ? (e->split ? 2 : 1) : 0;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
         HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));

@@ -217,10 +217,12 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
             int ref_steps = 0, query_steps = 0, nst = 0;
             ScoreWalk wk;
             wk.load(s);
-            if (!stop && w.gl == 0)
-                walk_chain<C, 0>(ws, tb_lds[wave_in_block * kGroupsPerWave + w.g], i0, j0, po.tB, kp.early,
-                                 ref_lds_g + kGroup + gt.shift, 1, q_lds_g, s.phase, kp, wk, ref_steps, query_steps,
-                                 nst);
+            if (!stop && w.gl == 0) {
+                const int l0 = (j0 - 1) / C;
+                walk_chain<C, 0>(ws, tb_lds[wave_in_block * kGroupsPerWave + w.g], i0, j0, l0, (j0 - 1) - l0 * C,
+                                 i0 + l0 - po.tB, kp.early, ref_lds_g + kGroup + gt.shift, 1, q_lds_g, s.phase, kp,
+                                 wk, ref_steps, query_steps, nst);
+            }
             chain_advance(s, stop, wk, ref_steps, query_steps, nst, 0);
             if (seed_mode && !s.first_tile) {
                 // first tile done: the rest of the chain belongs to the main launch

@@ -449,9 +449,11 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
                 const int sh = h ? pt.shift[1] : pt.shift[0];
                 const uint8_t *rrow = ref8 + (kGroup + sh) * 2 + h;
                 const uint8_t *qrow = q8 + h * G::kTileMax;
-                walk_chain<C, 1>(h ? wsB : wsA, tb_lds[group_in_block][h], h ? pt.R[1] : pt.R[0],
-                                 h ? pt.Q[1] : pt.Q[0], tB - sh, kp.early, rrow, 2, qrow, phase, kp, wk, ref_steps,
-                                 query_steps, nst);
+                const int Rh = h ? pt.R[1] : pt.R[0], Qh = h ? pt.Q[1] : pt.Q[0];
+                const int l0 = (Qh - 1) / C;
+                walk_chain<C, 1>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, (Qh - 1) - l0 * C,
+                                 Rh + l0 - (tB - sh), kp.early, rrow, 2, qrow, phase, kp, wk, ref_steps, query_steps,
+                                 nst);
             }
         }
         GACT_STAMP(t_f);

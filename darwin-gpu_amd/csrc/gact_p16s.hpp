@@ -1,0 +1,360 @@
+// gact_p16s.hpp -- "split" layout of the packed-int16 chain pass.
+//
+// In the uniform layout (gact_p16.hpp) every lane owns C consecutive columns,
+// and once the wave is inside the traceback window every column slot pays for
+// pointer generation -- also the slots of lanes whose columns lie left of the
+// window and can never be read (columns <= Q - early, align.cpp:205).  Here a
+// lane's C1 + C2 slots come from two column regions instead:
+//
+//   region 2 = the LAST 16*C2 columns of the tile (>= early, so it contains the
+//              whole window): lane l holds its columns l*C2+1 .. (l+1)*C2,
+//   region 1 = the columns left of it, right-aligned into 16*C1 slots
+//              (missing columns on the left are pads, which behave like the
+//              j = 0 border),
+//
+// run as two fused wavefronts: region 1 is at row t - l, region 2 at row
+// t - l - 16.  Lane 15 finishes a row of region 1 exactly one step before
+// lane 0 starts that row of region 2, so region 1's last column reaches
+// region 2's first one with the same one-step DPP hop as any other lane
+// boundary (row_ror:1 instead of row_shr:1).  Pointer work is emitted for the
+// C2 region-2 slots only: 7 x 12.5 + 13 x 26.5 instead of 20 x 26.5
+// instructions per step in the window phase, for 16 more steps per pass.
+//
+// Same cells, same arithmetic as dp_pass_p16 -- only the schedule differs.
+#pragma once
+
+#include "gact_p16.hpp"
+
+namespace gact {
+
+template <int C1, int C2> struct GeometrySplit {
+    static constexpr int CT = C1 + C2;
+    static constexpr int kTileMax = CT * kGroup;
+    static constexpr int W1 = C1 * kGroup, W2 = C2 * kGroup;
+    static constexpr int kLag = kGroup;
+    static constexpr int kMaxSteps = kTileMax + kGroup + kLag;
+    static constexpr int kQuads = (C2 + 3) / 4;
+    static constexpr int kRow0 = kGroup + kLag;                   // stream entry of (delay 0, row 1)
+    static constexpr int kRefEntries = kRow0 + kMaxSteps + kGroup + 8;
+    static constexpr int kRefBytes = kRefEntries * 2;
+    static constexpr int kQueryBytes = kTileMax * kSlots;
+    static constexpr int kGroupLds = (kRefBytes + kQueryBytes + 15) & ~15;
+    static constexpr int kMaxFlush = (kMaxSteps + 7) / 8 + 1;
+    static constexpr int kWsWords = kMaxFlush * kQuads * 4 * kGroup;
+};
+
+__device__ __forceinline__ int dpp_row_ror1(int v)
+{
+    // lane n of each 16-lane row reads lane n-1, lane 0 reads lane 15
+    return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);
+}
+
+template <int C2> __device__ __forceinline__ int split_last_step(int R, int Q)
+{
+    return (R > 0 && Q > 0) ? R + (kGroup - 1) + kGroup : 0;      // lane 15, region 2 (16 steps behind), row R
+}
+
+// first step whose pointers the traceback can reach, in the split layout
+template <int C2> __device__ __forceinline__ int split_first_pointer_step(int R, int Q, int early)
+{
+    const int r_first = imax(1, R - early + 1);
+    const int j_first = imax(1, Q - early + 1);
+    const int jj = j_first + (C2 * kGroup - Q);                   // 1-based index inside region 2
+    return r_first + (jj - 1) / C2 + kGroup;
+}
+
+// ---------------------------------------------------------------------------
+// ref16[t] / ref16[t - 16] hold the bases of region 1's / region 2's row at step t.
+template <int C1, int C2>
+__device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
+                                             const uint16_t *__restrict__ ref16,
+                                             const uint32_t (&qb)[C1 + C2],
+                                             const int T_end, const int tB,
+                                             uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB)
+{
+    constexpr int CT = C1 + C2;
+    constexpr int QD = (C2 + 3) / 4;
+    constexpr int LAG = kGroup;
+    uint32_t Hm[CT], Mo[CT], Iup[CT];       // H+match, M+open, I of the previous row (both tiles)
+    uint32_t accO[QD * 4], accF[QD * 4];    // pointer bits of the region-2 slots (see dp_pass_p16)
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        Hm[c] = kc.match; Mo[c] = kc.open; Iup[c] = kc.ninf;
+    }
+#pragma unroll
+    for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
+    // last slot of each region as the neighbour lane will see it
+    uint32_t Mo1 = kc.open, D1 = kc.ninf, H1 = kc.match;
+    uint32_t Mo2 = kc.open, D2 = kc.ninf, H2 = kc.match;
+    uint32_t Hdiag1 = kc.match, Hdiag2 = kc.match;
+    const bool last_lane = gl == kGroup - 1;
+
+    auto unpack = [](uint32_t w) { return (w & 0xffu) | ((w & 0xff00u) << 8); };
+    uint32_t rb1 = unpack(ref16[1]), rb2 = unpack(ref16[1 - LAG]);
+
+    auto step = [&](const int t, auto ptr_tag) {
+        constexpr bool PTR = decltype(ptr_tag)::value;
+        const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
+
+        // region 1: lane 0 sits on the j = 0 border (or on left pads, which behave like it)
+        const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)Mo1, (int)kc.open);
+        const uint32_t Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)kc.ninf);
+        const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)kc.match);
+        // region 2: lane 0 continues lane 15's region 1 (computed one step ago = same row)
+        const uint32_t Ml2 = (uint32_t)dpp_row_ror1((int)(last_lane ? Mo1 : Mo2));
+        const uint32_t Dl2 = (uint32_t)dpp_row_ror1((int)(last_lane ? D1 : D2));
+        const uint32_t Hl2 = (uint32_t)dpp_row_ror1((int)(last_lane ? H1 : H2));
+        uint32_t Hd = Hdiag1;
+        Hdiag1 = Hl1;
+
+        uint32_t M[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
+            const uint32_t neq = pk_min1(qb[c] ^ (c < C1 ? rb1 : rb2));        // align.cpp:134
+            const uint32_t Mx = pk_mad_s(neq, kc.nd, Hd);
+            Hd = Hm[c];
+            M[c] = pk_max0(Mx);                                                 // :145-147
+            const uint32_t Ie = pk_add_s(Iup[c], kc.ext);                       // :150
+            if (PTR && c >= C1) accF[c - C1] = pk_shl_add2(accF[c - C1], pk_sign(pk_sub(Mo[c], Ie)));   // :170
+            Iup[c] = pk_max(Mo[c], Ie);                                         // :154
+            Mo[c] = pk_add_s(M[c], kc.open);
+        }
+        uint32_t Ml = Ml1, Dl = Dl1;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c == C1) {
+                Mo1 = Ml; D1 = Dl; H1 = Hm[C1 - 1];
+                Ml = Ml2; Dl = Dl2;
+            }
+            const uint32_t De = pk_add_s(Dl, kc.ext);                           // :152
+            const uint32_t D = pk_max(Ml, De);                                  // :156
+            const uint32_t H = pk_max(pk_max(M[c], Iup[c]), D);                 // :158-160
+            if (PTR && c >= C1) {
+                accF[c - C1] = pk_shl_add2(accF[c - C1], pk_sign(pk_sub(Ml, De)));                      // :171
+                const uint32_t nz = pk_min1(H);                                 // :162-168, see dp_pass_p16
+                const uint32_t na = pk_min1(pk_sub(H, M[c]));
+                const uint32_t nb = pk_min1(pk_sub(H, Iup[c]));
+                const uint32_t o = pk_mad_vvv(na, nb, na);
+                accO[c - C1] = pk_shl_add4(accO[c - C1], pk_mad_vvv(nz, o, nz));
+            }
+            Hm[c] = pk_add_s(H, kc.match);
+            Ml = Mo[c];
+            Dl = D;
+        }
+        Mo2 = Ml; D2 = Dl; H2 = Hm[CT - 1];
+        rb1 = unpack(w1);
+        rb2 = unpack(w2);
+    };
+
+    auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
+    auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
+
+    int t = 1;
+    for (; t < tB && t <= T_end; t++) step(t, std::false_type{});
+    uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
+    uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
+    int k = 0;
+    for (; t <= T_end; t++, k++) {
+        step(t, std::true_type{});
+        if ((k & 7) == 7) {
+#pragma unroll
+            for (int q = 0; q < QD; q++) {
+                qA[q * kGroup] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
+                                            wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
+                qB[q * kGroup] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
+                                            wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
+            }
+            qA += QD * kGroup;
+            qB += QD * kGroup;
+        }
+    }
+    if (k & 7) {
+        const int sh = 2 * (8 - (k & 7));
+        auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            qA[q * kGroup] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+                                        just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
+            qB[q * kGroup] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+                                        just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Column slot s of lane gl holds padded column p (1..16*CT, columns right-aligned:
+// DP column j = p - (16*CT - Q), p <= 0 .. are pads).
+template <int C1, int C2>
+__device__ __forceinline__ void load_pair_split(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc,
+                                                bool raw, const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8,
+                                                uint32_t (&qb)[C1 + C2])
+{
+    using G = GeometrySplit<C1, C2>;
+    constexpr int CT = C1 + C2;
+    uint32_t *ref32 = reinterpret_cast<uint32_t *>(ref8);
+    for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = 0xffffffffu;
+    wave_sync();
+    uint32_t rv[kSlots][CT], qv[kSlots][CT];
+    int dq[kSlots][CT];
+    auto issue = [&](auto raw_tag) {
+        constexpr bool RAW = decltype(raw_tag)::value;
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
+            const int S = G::kTileMax - pt.Q[h];
+#pragma unroll
+            for (int s = 0; s < CT; s++) {
+                const int p = (s < C1) ? gl * C1 + s + 1 : G::W1 + gl * C2 + (s - C1) + 1;
+                dq[h][s] = p - S - 1;                                      // 0-based DP column, < 0 = left pad
+                rv[h][s] = fetch_base<RAW>(rs, slice_pos(pt.rp0[h], pt.R[h], pt.reverse[h], gl * CT + s));
+                qv[h][s] = fetch_base<RAW>(qs, slice_pos(pt.qp0[h], pt.Q[h], pt.reverse[h], imax(dq[h][s], 0)));
+            }
+        }
+    };
+    if (raw) issue(std::true_type{}); else issue(std::false_type{});
+#pragma unroll
+    for (int s = 0; s < CT; s++) qb[s] = 0;
+#pragma unroll
+    for (int h = 0; h < kSlots; h++) {
+        const int R = pt.R[h];
+        uint8_t *rrow = ref8 + (G::kRow0 + pt.shift[h]) * 2 + h;
+#pragma unroll
+        for (int s = 0; s < CT; s++) {
+            const int d = gl * CT + s;                                     // DP row handled by this slot of the loader
+            if (d < R) rrow[d * 2] = (uint8_t)rv[h][s];
+            const bool real = dq[h][s] >= 0;
+            const uint32_t qcode = real ? qv[h][s] : kQueryPad;
+            if (real) q8[h * G::kTileMax + dq[h][s]] = (uint8_t)qcode;
+            qb[s] |= qcode << (16 * h);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// extend_p16_kernel with the split pass.  Requires early <= 16*C2 (window inside region 2).
+template <int C1, int C2>
+__global__ __launch_bounds__(kBlockThreads, 3) void extend_p16s_kernel(
+    KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
+    int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
+    uint32_t *__restrict__ ws_all)
+{
+    using G = GeometrySplit<C1, C2>;
+    constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
+    __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
+
+    const WaveCtx w = wave_ctx();
+    const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
+    uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
+    uint8_t *q8 = ref8 + G::kRefBytes;
+    const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (G::kRow0 - 1 - w.gl);
+    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
+    uint32_t *wsB = wsA + kp.ws_words;
+    const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
+
+    ChainState *st = chain_lds[group_in_block];
+    if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
+    wave_sync();
+    bool exhausted = false;
+    int my_bucket = 0;           // longest chains first (ChainQueues)
+    __builtin_amdgcn_s_setprio(3);
+
+    for (;;) {
+        PairTile pt;
+        bool have[kSlots];
+        int Tend_h[kSlots], tB_h[kSlots];
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            ChainState s = st[h];
+            TilePick pk;
+            pk.have = false; pk.R = 0; pk.Q = 0; pk.reverse = false; pk.rp0 = 0; pk.qp0 = 0;
+            for (int guard = 0; guard < 3 && !pk.have; guard++) {
+                if (s.phase == 2) {
+                    if (exhausted) break;
+                    int cand = -1;
+                    while (my_bucket < kBuckets) {
+                        int idx = 0;
+                        if (w.gl == 0) idx = atomicAdd(&cq.bucket_pop[my_bucket], 1);
+                        idx = __shfl(idx, 0, kGroup);
+                        if (idx < cq.bucket_count[my_bucket]) {
+                            cand = cq.live[(size_t)my_bucket * cq.live_stride + idx];
+                            break;
+                        }
+                        my_bucket++;
+                    }
+                    if (cand < 0) { exhausted = true; break; }
+                    s = cq.states[cand];
+                }
+                pk = chain_pick(s, kp, same_file, out, w.gl == 0);
+            }
+            have[h] = pk.have;
+            pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
+            pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
+            Tend_h[h] = split_last_step<C2>(pk.R, pk.Q);
+            tB_h[h] = split_first_pointer_step<C2>(pk.R, pk.Q, kp.early);
+            wave_sync();
+            if (w.gl == 0) st[h] = s;
+            wave_sync();
+        }
+        const bool any_here = have[0] | have[1];
+        if (!__any(any_here)) {
+            if (__all(exhausted && st[0].phase == 2 && st[1].phase == 2)) break;
+            continue;
+        }
+        // common end / common pointer start over the wave's 8 tiles (align_starts)
+        const int T_end = wave_max4(imax(have[0] ? Tend_h[0] : 0, have[1] ? Tend_h[1] : 0));
+        const int reach0 = have[0] ? tB_h[0] + (T_end - Tend_h[0]) : 0x7fffffff;
+        const int reach1 = have[1] ? tB_h[1] + (T_end - Tend_h[1]) : 0x7fffffff;
+        const int tB = wave_min4(imin(reach0, reach1));
+        pt.shift[0] = have[0] ? imax(0, tB - tB_h[0]) : 0;
+        pt.shift[1] = have[1] ? imax(0, tB - tB_h[1]) : 0;
+
+        uint32_t qb[C1 + C2];
+        load_pair_split<C1, C2>(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
+        wave_sync();
+
+        __builtin_amdgcn_s_setprio(0);
+        dp_pass_p16s<C1, C2>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
+        __builtin_amdgcn_s_setprio(3);
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pointer stores -> L2 before the sc1 loads
+
+        // ---- traceback: lane h of the group walks slot h, all walkers of the wave in one loop
+        int ref_steps = 0, query_steps = 0, nst = 0;
+        ScoreWalk wk;
+        wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
+        {
+            const int h = w.gl & 1;
+            const bool mine = (w.gl < kSlots) && (h ? have[1] : have[0]);
+            if (mine) {
+                const ChainState &s = st[h];
+                wk.load(s);
+                const int sh = h ? pt.shift[1] : pt.shift[0];
+                const int Rh = h ? pt.R[1] : pt.R[0], Qh = h ? pt.Q[1] : pt.Q[0];
+                const uint8_t *rrow = ref8 + (G::kRow0 + sh) * 2 + h;
+                const uint8_t *qrow = q8 + h * G::kTileMax;
+                // the start cell (R, Q) is the last column of region 2: lane 15, slot C2-1
+                const int tB_tile = tB - sh - G::kLag;
+                walk_chain<C2, 1, G::kQuads>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, kGroup - 1, C2 - 1,
+                                             Rh + (kGroup - 1) - tB_tile, kp.early, rrow, 2, qrow, s.phase, kp, wk,
+                                             ref_steps, query_steps, nst);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            if (have[h]) {
+                ChainState s = st[h];
+                s.n_tiles++;
+                s.cells += (int64_t)pt.R[h] * pt.Q[h];
+                chain_advance(s, false, wk, ref_steps, query_steps, nst, h);
+                wave_sync();
+                if (w.gl == 0) st[h] = s;
+            }
+            wave_sync();
+        }
+    }
+}
+
+}  // namespace gact

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # darwin-gp
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp")] + \
+           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
 SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2
@@ -264,7 +264,8 @@ class Engine:
         st = RunStats()
         self._check(self.L.gact_hip_last_run_stats(self.h, slot, C.byref(st)))
         return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
-                "packed16": bool(st.packed16), "handed_off": st.handed_off, "seed_cells": st.seed_cells}
+                "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split")[st.packed16],
+                "handed_off": st.handed_off, "seed_cells": st.seed_cells}
 
     def measure_valu_rate(self):
         v = C.c_double()

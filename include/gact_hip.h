@@ -198,7 +198,8 @@ int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);
  * (packed-int16 kernel, every later tile). */
 typedef struct {
     float total_ms, seed_ms, main_ms;   /* HIP events on the slot's stream */
-    int32_t packed16;                   /* 1: seed + packed-int16 main launch, 0: one int32 launch */
+    int32_t packed16;                   /* 0: one int32 launch; 1: seed + packed-int16 main launch, uniform
+                                           column layout; 2: the same, split (two-region) layout */
     int32_t handed_off;                 /* candidates the main launch continued */
     int64_t seed_cells;                 /* DP cells executed by the seed launch */
 } gact_hip_run_stats;

@@ -38,13 +38,16 @@ def _run(rs, cf, cr, oracle, scoring=(1, -1, -1, -1), tile=320, overlap=120, thr
     return total
 
 
-@pytest.fixture(params=["packed16", "int32"], autouse=True)
+@pytest.fixture(params=["packed16", "packed16-uniform", "int32"], autouse=True)
 def kernel_family(request, monkeypatch):
-    """every chain test runs twice: seed + packed-int16 main launch (default), and the int32 kernel alone"""
+    """every chain test runs three times: seed + packed-int16 main launch in its split layout (default where
+    the geometry allows it), the same in the uniform layout, and the int32 kernel alone"""
+    monkeypatch.delenv("GACT_HIP_FORCE_INT32", raising=False)
+    monkeypatch.delenv("GACT_HIP_FORCE_UNIFORM", raising=False)
     if request.param == "int32":
         monkeypatch.setenv("GACT_HIP_FORCE_INT32", "1")
-    else:
-        monkeypatch.delenv("GACT_HIP_FORCE_INT32", raising=False)
+    elif request.param == "packed16-uniform":
+        monkeypatch.setenv("GACT_HIP_FORCE_UNIFORM", "1")
     return request.param
 
 
@@ -57,7 +60,7 @@ def test_kernel_family_is_the_one_asked_for(kernel_family):
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
     eng.extend(cf)
     st = eng.last_run_stats()
-    assert st["packed16"] == (kernel_family == "packed16")
+    assert st["layout"] == {"packed16": "packed16-split", "packed16-uniform": "packed16-uniform", "int32": "int32"}[kernel_family]
     if st["packed16"]:
         assert 0 < st["handed_off"] <= len(cf) and st["seed_cells"] > 0
     eng.close()

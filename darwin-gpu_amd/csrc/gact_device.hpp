@@ -388,8 +388,8 @@ __device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int 
 }
 
 // ---------------------------------------------------------------------------
-// Region-cached traceback.  Several walkers (one lane each) run this loop in
-// lock step, so a per-step pointer load would cost every walker a full memory
+// Region cache of the chain kernels' walker (walk_chain, gact_chain.hpp).  Several
+// walkers (one lane each) run in lock step, so a per-step pointer load would cost every walker a full memory
 // round trip whenever ANY of them misses.  Instead every kTbSpan steps each
 // walker copies the whole region it can reach in the next kTbSpan steps
 // (rows i-8..i, columns j-8..j: 2 lanes x 2 flush blocks x 3 column quads =
@@ -461,56 +461,6 @@ __device__ __forceinline__ uint32_t tb_lookup_at(const uint32_t *scratch, int l,
     const uint32_t code = (w >> sh) & 3u, nfl = ~(w >> (sh + 16)) & 3u;
     const uint32_t state = code ? 4u - code : 0u;              // -> align.h:23 numbering Z0 D1 I2 M3
     return state | (nfl << 2);                                 // bit3 ins flag, bit2 del flag
-}
-
-template <int C>
-__device__ __forceinline__ void tb_refill(const uint32_t *ws, uint32_t *scratch, int i, int j, int tB, TbRegion<C> &rg)
-{
-    const int l0 = (j - 1) / C;
-    tb_refill_at<C>(ws, scratch, l0, (j - 1) - l0 * C, i + l0 - tB, rg);
-}
-template <int C, int FMT>
-__device__ __forceinline__ uint32_t tb_lookup(const uint32_t *scratch, int i, int j, int tB, const TbRegion<C> &rg)
-{
-    const int l = (j - 1) / C;
-    return tb_lookup_at<C, FMT>(scratch, l, (j - 1) - l * C, i + l - tB, rg);
-}
-
-// Same walk as traceback() above (align.cpp:185-230); `scratch` is this lane's
-// kTbScratchWords dwords of LDS.  All lanes that enter take the same number of
-// steps between refills, so the refill branch is uniform among them.
-template <int C, int FMT, class Emit>
-__device__ __forceinline__ void traceback_cached(const uint32_t *ws, uint32_t *scratch, int i, int j, int tB,
-                                                 int early, int &ref_steps, int &query_steps, Emit &&emit)
-{
-    int is = 0, js = 0;
-    int state = GACT_STATE_Z;
-    uint32_t nib = 0;
-    TbRegion<C> rg;
-    int since = 0;
-    if (i >= 1 && j >= 1 && early > 0) {
-        tb_refill<C>(ws, scratch, i, j, tB, rg);
-        nib = tb_lookup<C, FMT>(scratch, i, j, tB, rg);
-        state = nib & 3;
-    }
-    while (state != GACT_STATE_Z) {
-        emit(state, i, j);
-        const bool isM = state == GACT_STATE_M, isI = state == GACT_STATE_I, isD = state == GACT_STATE_D;
-        const int next = isM ? -1 : (isI ? ((nib & 8) ? GACT_STATE_M : GACT_STATE_I)
-                                         : ((nib & 4) ? GACT_STATE_M : GACT_STATE_D));
-        const int di = (isM | isI) ? 1 : 0, dj = (isM | isD) ? 1 : 0;
-        i -= di; j -= dj; is += di; js += dj;
-        if (is >= early || js >= early) break;       // align.cpp:205
-        if (i < 1 || j < 1) break;                   // border pointers are ZERO (align.cpp:101-107)
-        if (++since == kTbSpan) {
-            tb_refill<C>(ws, scratch, i, j, tB, rg);
-            since = 0;
-        }
-        nib = tb_lookup<C, FMT>(scratch, i, j, tB, rg);
-        state = (next < 0) ? (int)(nib & 3) : next;
-    }
-    ref_steps = is;
-    query_steps = js;
 }
 
 // ---------------------------------------------------------------------------

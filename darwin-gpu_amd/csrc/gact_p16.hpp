@@ -119,22 +119,6 @@ __device__ __forceinline__ uint32_t pk_shl_add4(uint32_t acc, uint32_t code)   /
     return r;
 }
 
-// lane masks of half-word compares
-#define GACT_CMP16(name, op, sel)                                                                 \
-    __device__ __forceinline__ uint64_t name(uint32_t a, uint32_t b)                               \
-    {                                                                                             \
-        uint64_t m;                                                                               \
-        asm(op " %0, %1, %2 src0_sel:" sel " src1_sel:" sel : "=s"(m) : "v"(a), "v"(b));          \
-        return m;                                                                                 \
-    }
-GACT_CMP16(ge_lo, "v_cmp_ge_i16_sdwa", "WORD_0")
-GACT_CMP16(ge_hi, "v_cmp_ge_i16_sdwa", "WORD_1")
-GACT_CMP16(gt_lo, "v_cmp_gt_i16_sdwa", "WORD_0")
-GACT_CMP16(gt_hi, "v_cmp_gt_i16_sdwa", "WORD_1")
-GACT_CMP16(eq_lo, "v_cmp_eq_u16_sdwa", "WORD_0")
-GACT_CMP16(eq_hi, "v_cmp_eq_u16_sdwa", "WORD_1")
-#undef GACT_CMP16
-
 template <int C> struct GeometryP16 {
     static constexpr int kTileMax = C * kGroup;
     static constexpr int kMaxSteps = kTileMax + kGroup;

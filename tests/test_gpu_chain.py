@@ -87,7 +87,10 @@ def test_chain_other_scoring(oracle, scoring):
     _run(rs, cf, cr, oracle, scoring=scoring)
 
 
-@pytest.mark.parametrize("tile,overlap,thr", [(320, 120, 35), (128, 32, 20), (200, 100, 35), (320, 200, 60)])
+@pytest.mark.parametrize("tile,overlap,thr", [(320, 120, 35), (128, 32, 20), (200, 100, 35), (320, 200, 60),
+                                              (320, 100, 35),     # early 220 > 208: uniform packed layout
+                                              (400, 150, 35),     # tile > 320: the 32-column kernels
+                                              (512, 256, 50)])
 def test_chain_other_geometry(oracle, tile, overlap, thr):
     from gact_amd import synth
     rs = synth.simulate_reads(15000, n_reads=12, seed=21, mean_len=3000, sd_len=800, min_len=800, max_len=6000)

@@ -56,7 +56,8 @@ def test_tiles_with_non_acgt(oracle):
     eng.close()
 
 
-@pytest.mark.parametrize("tile,overlap", [(320, 120), (320, 0), (320, 319), (128, 32), (64, 8), (96, 48)])
+@pytest.mark.parametrize("tile,overlap", [(320, 120), (320, 0), (320, 319), (128, 32), (64, 8), (96, 48), (448, 128),
+                                          (512, 200)])
 def test_other_tile_geometries(oracle, tile, overlap):
     from gact_amd import engine
     eng = engine.Engine(tile_size=tile, tile_overlap=overlap)

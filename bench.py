@@ -59,6 +59,10 @@ def main():
     use_dist = world > 1 or args.force_dist
     if world != args.gpus and world > 1:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("bench.py: --gpus %d needs one process per GPU: launch with\n  python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus, args.gpus))
 
     torch = dist = None
     if use_dist:

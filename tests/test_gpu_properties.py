@@ -1,0 +1,94 @@
+"""GPU suite: size-independent properties of the chain engine on a workload too large to run through the oracle
+in a unit test (1/20-scale E.coli-shape, ~5,000 D-SOFT candidates, ~1.6e10 cells): what the multi-GPU deal and
+the persistent scheduling rely on."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from gact_amd import engine, workload
+    blk = workload.make_block("ecoli10x_small")
+    eng = engine.Engine()
+    cat, offs = blk.rs.concat(); rcat, roffs = blk.rs.concat(rc=True)
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
+    eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+    cands = np.concatenate([blk.cf, blk.cr])
+    nf = len(blk.cf)
+    eng.candidates_upload(cands)
+    eng.candidates_run_mixed(len(cands), rc_from=nf)
+    base = eng.candidates_fetch(len(cands))
+    yield eng, blk, cands, nf, base
+    eng.close()
+
+
+def test_workload_is_substantial(setup):
+    eng, blk, cands, nf, base = setup
+    assert len(cands) > 2000 and base["cells"].sum() > 5e9
+    assert base["emitted"].sum() > 0.5 * len(cands)
+    # every executed tile is at most tile_size^2 cells and every chain ran at least one tile
+    assert (base["cells"] <= base["n_tiles"].astype(np.int64) * 320 * 320).all()
+    assert (base["n_tiles"] >= 1).all()
+    # extents stay inside the reads and are ordered
+    rl = np.array([len(r) for r in blk.rs.reads])
+    assert (base["ab"] >= 0).all() and (base["ab"] <= base["ae"]).all() and (base["ae"] <= rl[base["ref_id"]]).all()
+    assert (base["bb"] >= 0).all() and (base["bb"] <= base["be"]).all() and (base["be"] <= rl[base["query_id"]]).all()
+
+
+def test_deterministic(setup):
+    """persistent scheduling (atomic queues, longest-first buckets) must not leak into the results"""
+    eng, blk, cands, nf, base = setup
+    for _ in range(3):
+        eng.candidates_run_mixed(len(cands), rc_from=nf)
+        assert eng.candidates_fetch(len(cands)).tobytes() == base.tobytes()
+
+
+def test_order_invariance(setup):
+    """a candidate's record does not depend on where it sits in the list"""
+    from gact_amd import engine
+    eng, blk, cands, nf, base = setup
+    rng = np.random.default_rng(3)
+    for comp, sl in ((False, slice(0, nf)), (True, slice(nf, len(cands)))):
+        part = cands[sl]
+        perm = rng.permutation(len(part))
+        got = eng.extend(part[perm], complement=comp, slot=0)
+        assert got.tobytes() == base[sl][perm].tobytes()
+    eng.candidates_upload(cands)     # restore the module fixture's upload
+
+
+def test_shard_invariance(setup):
+    """dealing the list round-robin over N ranks and re-interleaving the records equals the single run"""
+    from gact_amd import dist as gdist
+    eng, blk, cands, nf, base = setup
+    for world in (2, 8):
+        parts_f, parts_r = [], []
+        for r in range(world):
+            cf, cr = gdist.deal(blk.cf, r, world), gdist.deal(blk.cr, r, world)
+            eng.candidates_upload(np.concatenate([cf, cr]))
+            eng.candidates_run_mixed(len(cf) + len(cr), rc_from=len(cf))
+            rec = eng.candidates_fetch(len(cf) + len(cr))
+            parts_f.append(rec[:len(cf)]); parts_r.append(rec[len(cf):])
+        assert gdist.undeal(parts_f, nf).tobytes() == base[:nf].tobytes()
+        assert gdist.undeal(parts_r, len(cands) - nf).tobytes() == base[nf:].tobytes()
+    eng.candidates_upload(cands)
+
+
+def test_kernel_families_agree_at_size(setup, monkeypatch):
+    """int32 kernel, packed-uniform and packed-split produce identical records on the whole workload"""
+    from gact_amd import engine
+    eng, blk, cands, nf, base = setup
+    cat, offs = blk.rs.concat(); rcat, roffs = blk.rs.concat(rc=True)
+    for var in ("GACT_HIP_FORCE_INT32", "GACT_HIP_FORCE_UNIFORM"):
+        monkeypatch.setenv(var, "1")
+        e2 = engine.Engine()
+        monkeypatch.delenv(var)
+        e2.upload(engine.SET_REF, cat, offs); e2.upload(engine.SET_QUERY, cat, offs)
+        e2.upload(engine.SET_QUERY_RC, rcat, roffs)
+        e2.candidates_upload(cands)
+        e2.candidates_run_mixed(len(cands), rc_from=nf)
+        got = e2.candidates_fetch(len(cands))
+        assert e2.last_run_stats()["layout"] != "packed16-split"
+        assert got.tobytes() == base.tobytes()
+        e2.close()

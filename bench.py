@@ -166,8 +166,8 @@ def main():
             "unit": "TOP/s (int32-equivalent lane-ops, 24 per DP cell)", "frac": round(achieved_tops / peak_tops, 4),
             "frac_packed16": round(achieved_tops / (2 * peak_tops), 4),
             "traffic": None,
-            "kernel": {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel",
-                       "packed16-split": "extend_p16s_kernel"}[kernel_ms[-1]["layout"]],
+            "kernel": {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
+                       "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>"}[kernel_ms[-1]["layout"]],
             "kernel_ms": round(float(k_ms), 3),
             "kernel_cells": main_cells, "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
             "measured_valu_peak_tops": round(measured_rate / 1e12, 3),

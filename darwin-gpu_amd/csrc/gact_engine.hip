@@ -249,11 +249,11 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     if (e->p16) {
         HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
         if (e->split)
-            hipLaunchKernelGGL((gact::extend_p16s_kernel<7, 13>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
+            hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayout<7, 13>>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
                                sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
                                same_file, sl.overlaps.p, queues(sl), sl.d_ws);
         else
-            hipLaunchKernelGGL((gact::extend_p16_kernel<C>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
+            hipLaunchKernelGGL((gact::extend_p16_kernel<gact::UniformLayout<C>>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
                                sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
                                same_file, sl.overlaps.p, queues(sl), sl.d_ws);
         HIP_TRY(hipGetLastError());
@@ -267,9 +267,9 @@ template <int C> int occupancy_blocks(int *out)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
     int c = a;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::extend_p16_kernel<C>, gact::kBlockThreads, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::extend_p16_kernel<gact::UniformLayout<C>>, gact::kBlockThreads, 0));
     int d = c;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, gact::extend_p16s_kernel<7, 13>, gact::kBlockThreads, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, gact::extend_p16_kernel<gact::SplitLayout<7, 13>>, gact::kBlockThreads, 0));
     *out = std::max(1, std::min(std::min(a, b), std::min(c, d)));
     return 0;
 }

@@ -317,14 +317,36 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 }
 
 // ---------------------------------------------------------------------------
+// Column layout policy of the packed pass: how a tile's columns map to (lane, slot),
+// which pass / loader go with it, and where the walker finds a cell's pointer word.
+template <int C> struct UniformLayout {
+    using G = GeometryP16<C>;
+    static constexpr int kSlotsPerLane = C;
+    static constexpr int kWalkCols = C, kWalkQuads = C / 4;       // columns / stored quads per lane for the walker
+    static constexpr int kRow0 = kGroup;                          // ref stream entry of (delay 0, row 1)
+    __device__ static int last_step(int R, int Q) { return gact::last_step<C>(R, Q); }
+    __device__ static int first_pointer_step(int R, int Q, int early) { return gact::first_pointer_step<C>(R, Q, early, false); }
+    __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr, bool raw,
+                                const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C])
+    { load_pair<C>(rs, qf, qr, raw, pt, gl, ref8, q8, qb); }
+    __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C], int T_end,
+                                int tB, uint32_t *wsA, uint32_t *wsB)
+    { dp_pass_p16<C>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    // start cell (R, Q) of the traceback: lane, column in lane, stored step (tB_tile = tile's own first stored step)
+    __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
+    { l = (Q - 1) / C; c = (Q - 1) - l * C; k = R + l - tB_tile; }
+    __device__ static int tile_tB(int tB, int shift) { return tB - shift; }
+};
+
+// ---------------------------------------------------------------------------
 // Persistent main kernel: every group carries two candidates (slot A / slot B).
-template <int C>
+template <class L>
 __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
     uint32_t *__restrict__ ws_all)
 {
-    using G = GeometryP16<C>;
+    using G = typename L::G;
     constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
     const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
     uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
     uint8_t *q8 = ref8 + G::kRefBytes;
-    const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (kGroup - 1 - w.gl);
+    const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (L::kRow0 - 1 - w.gl);
     uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
     uint32_t *wsB = wsA + kp.ws_words;
     const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
@@ -383,8 +405,8 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
             have[h] = pk.have;
             pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
             pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
-            Tend_h[h] = last_step<C>(pk.R, pk.Q);
-            tB_h[h] = first_pointer_step<C>(pk.R, pk.Q, kp.early, false);
+            Tend_h[h] = L::last_step(pk.R, pk.Q);
+            tB_h[h] = L::first_pointer_step(pk.R, pk.Q, kp.early);
             wave_sync();
             if (w.gl == 0) st[h] = s;
             wave_sync();
@@ -403,8 +425,8 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
         pt.shift[1] = have[1] ? imax(0, tB - tB_h[1]) : 0;
 
         GACT_STAMP(t_b);
-        uint32_t qb[C];
-        load_pair<C>(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
+        uint32_t qb[L::kSlotsPerLane];
+        L::load(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
         wave_sync();
         GACT_STAMP(t_c);
 
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
         // chain (traceback, chain bookkeeping, loads) that must not queue behind other
         // waves' DP instructions: run it at raised issue priority
         __builtin_amdgcn_s_setprio(0);
-        dp_pass_p16<C>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
+        L::pass(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
         __builtin_amdgcn_s_setprio(3);
         GACT_STAMP(t_d);
 
@@ -429,15 +451,15 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
             if (mine) {
                 const ChainState &s = st[h];
                 wk.load(s);
-                const int phase = s.phase;
                 const int sh = h ? pt.shift[1] : pt.shift[0];
-                const uint8_t *rrow = ref8 + (kGroup + sh) * 2 + h;
-                const uint8_t *qrow = q8 + h * G::kTileMax;
                 const int Rh = h ? pt.R[1] : pt.R[0], Qh = h ? pt.Q[1] : pt.Q[0];
-                const int l0 = (Qh - 1) / C;
-                walk_chain<C, 1>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, (Qh - 1) - l0 * C,
-                                 Rh + l0 - (tB - sh), kp.early, rrow, 2, qrow, phase, kp, wk, ref_steps, query_steps,
-                                 nst);
+                const uint8_t *rrow = ref8 + (L::kRow0 + sh) * 2 + h;
+                const uint8_t *qrow = q8 + h * G::kTileMax;
+                int l0, c0, k0;
+                L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
+                walk_chain<L::kWalkCols, 1, L::kWalkQuads>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
+                                                           kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
+                                                           query_steps, nst);
             }
         }
         GACT_STAMP(t_f);

@@ -232,129 +232,24 @@ __device__ __forceinline__ void load_pair_split(const SeqSetDev &rs, const SeqSe
 }
 
 // ---------------------------------------------------------------------------
-// extend_p16_kernel with the split pass.  Requires early <= 16*C2 (window inside region 2).
-template <int C1, int C2>
-__global__ __launch_bounds__(kBlockThreads, 3) void extend_p16s_kernel(
-    KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
-    int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
-    uint32_t *__restrict__ ws_all)
-{
+// Layout policy for extend_p16_kernel (gact_p16.hpp).  Requires early <= 16*C2 (window inside region 2).
+template <int C1, int C2> struct SplitLayout {
     using G = GeometrySplit<C1, C2>;
-    constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
-    __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
-    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
-
-    const WaveCtx w = wave_ctx();
-    const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
-    uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
-    uint8_t *q8 = ref8 + G::kRefBytes;
-    const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (G::kRow0 - 1 - w.gl);
-    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
-    uint32_t *wsB = wsA + kp.ws_words;
-    const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
-
-    ChainState *st = chain_lds[group_in_block];
-    if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
-    wave_sync();
-    bool exhausted = false;
-    int my_bucket = 0;           // longest chains first (ChainQueues)
-    __builtin_amdgcn_s_setprio(3);
-
-    for (;;) {
-        PairTile pt;
-        bool have[kSlots];
-        int Tend_h[kSlots], tB_h[kSlots];
-#pragma unroll
-        for (int h = 0; h < kSlots; h++) {
-            ChainState s = st[h];
-            TilePick pk;
-            pk.have = false; pk.R = 0; pk.Q = 0; pk.reverse = false; pk.rp0 = 0; pk.qp0 = 0;
-            for (int guard = 0; guard < 3 && !pk.have; guard++) {
-                if (s.phase == 2) {
-                    if (exhausted) break;
-                    int cand = -1;
-                    while (my_bucket < kBuckets) {
-                        int idx = 0;
-                        if (w.gl == 0) idx = atomicAdd(&cq.bucket_pop[my_bucket], 1);
-                        idx = __shfl(idx, 0, kGroup);
-                        if (idx < cq.bucket_count[my_bucket]) {
-                            cand = cq.live[(size_t)my_bucket * cq.live_stride + idx];
-                            break;
-                        }
-                        my_bucket++;
-                    }
-                    if (cand < 0) { exhausted = true; break; }
-                    s = cq.states[cand];
-                }
-                pk = chain_pick(s, kp, same_file, out, w.gl == 0);
-            }
-            have[h] = pk.have;
-            pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
-            pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
-            Tend_h[h] = split_last_step<C2>(pk.R, pk.Q);
-            tB_h[h] = split_first_pointer_step<C2>(pk.R, pk.Q, kp.early);
-            wave_sync();
-            if (w.gl == 0) st[h] = s;
-            wave_sync();
-        }
-        const bool any_here = have[0] | have[1];
-        if (!__any(any_here)) {
-            if (__all(exhausted && st[0].phase == 2 && st[1].phase == 2)) break;
-            continue;
-        }
-        // common end / common pointer start over the wave's 8 tiles (align_starts)
-        const int T_end = wave_max4(imax(have[0] ? Tend_h[0] : 0, have[1] ? Tend_h[1] : 0));
-        const int reach0 = have[0] ? tB_h[0] + (T_end - Tend_h[0]) : 0x7fffffff;
-        const int reach1 = have[1] ? tB_h[1] + (T_end - Tend_h[1]) : 0x7fffffff;
-        const int tB = wave_min4(imin(reach0, reach1));
-        pt.shift[0] = have[0] ? imax(0, tB - tB_h[0]) : 0;
-        pt.shift[1] = have[1] ? imax(0, tB - tB_h[1]) : 0;
-
-        uint32_t qb[C1 + C2];
-        load_pair_split<C1, C2>(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
-        wave_sync();
-
-        __builtin_amdgcn_s_setprio(0);
-        dp_pass_p16s<C1, C2>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
-        __builtin_amdgcn_s_setprio(3);
-
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pointer stores -> L2 before the sc1 loads
-
-        // ---- traceback: lane h of the group walks slot h, all walkers of the wave in one loop
-        int ref_steps = 0, query_steps = 0, nst = 0;
-        ScoreWalk wk;
-        wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
-        {
-            const int h = w.gl & 1;
-            const bool mine = (w.gl < kSlots) && (h ? have[1] : have[0]);
-            if (mine) {
-                const ChainState &s = st[h];
-                wk.load(s);
-                const int sh = h ? pt.shift[1] : pt.shift[0];
-                const int Rh = h ? pt.R[1] : pt.R[0], Qh = h ? pt.Q[1] : pt.Q[0];
-                const uint8_t *rrow = ref8 + (G::kRow0 + sh) * 2 + h;
-                const uint8_t *qrow = q8 + h * G::kTileMax;
-                // the start cell (R, Q) is the last column of region 2: lane 15, slot C2-1
-                const int tB_tile = tB - sh - G::kLag;
-                walk_chain<C2, 1, G::kQuads>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, kGroup - 1, C2 - 1,
-                                             Rh + (kGroup - 1) - tB_tile, kp.early, rrow, 2, qrow, s.phase, kp, wk,
-                                             ref_steps, query_steps, nst);
-            }
-        }
-#pragma unroll
-        for (int h = 0; h < kSlots; h++) {
-            if (have[h]) {
-                ChainState s = st[h];
-                s.n_tiles++;
-                s.cells += (int64_t)pt.R[h] * pt.Q[h];
-                chain_advance(s, false, wk, ref_steps, query_steps, nst, h);
-                wave_sync();
-                if (w.gl == 0) st[h] = s;
-            }
-            wave_sync();
-        }
-    }
-}
+    static constexpr int kSlotsPerLane = C1 + C2;
+    static constexpr int kWalkCols = C2, kWalkQuads = G::kQuads;
+    static constexpr int kRow0 = G::kRow0;
+    __device__ static int last_step(int R, int Q) { return split_last_step<C2>(R, Q); }
+    __device__ static int first_pointer_step(int R, int Q, int early) { return split_first_pointer_step<C2>(R, Q, early); }
+    __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr, bool raw,
+                                const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C1 + C2])
+    { load_pair_split<C1, C2>(rs, qf, qr, raw, pt, gl, ref8, q8, qb); }
+    __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
+                                int T_end, int tB, uint32_t *wsA, uint32_t *wsB)
+    { dp_pass_p16s<C1, C2>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    // the start cell (R, Q) is the last column of region 2: lane 15, slot C2-1
+    __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
+    { (void)Q; l = kGroup - 1; c = C2 - 1; k = R + (kGroup - 1) - tB_tile; }
+    __device__ static int tile_tB(int tB, int shift) { return tB - shift - G::kLag; }
+};
 
 }  // namespace gact

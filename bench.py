@@ -146,7 +146,6 @@ def main():
 
     if rank == 0:
         gcups = tot_cells * args.steps / max_dt / 1e9
-        # dominant kernel: extend_kernel; HIP events on its own stream, this rank
         # dominant kernel: the main launch (packed-int16 extend_p16_kernel, or the int32 extend_kernel when
         # the scoring does not fit int16); HIP events on its own stream, this rank
         packed = kernel_ms[-1]["packed16"]
@@ -169,7 +168,8 @@ def main():
             "kernel": {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
                        "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>"}[kernel_ms[-1]["layout"]],
             "kernel_ms": round(float(k_ms), 3),
-            "kernel_cells": main_cells, "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
+            "kernel_cells": main_cells, "seed_kernel": {"packed16": "seed_p16_kernel<20>", "int32": "extend_kernel<20>"}[kernel_ms[-1]["seed_layout"]],
+            "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
             "measured_valu_peak_tops": round(measured_rate / 1e12, 3),
             "peak_gcups": round(peak_tops * 1e3 / OPS_PER_CELL, 1),
             "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
@@ -180,7 +180,9 @@ def main():
             "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(max_dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16x2 (packed) main kernel, int32 seed kernel" if packed else "int32", "data": "synthetic",
+            "dtype": ("int16x2 (packed)" if kernel_ms[-1]["seed_layout"] == "packed16"
+                      else "int16x2 (packed) main kernel, int32 seed kernel") if packed else "int32",
+            "data": "synthetic",
             "config": {"workload": args.workload + "_self_overlap", "candidate_source": args.candidates, "tile_size": 320, "tile_overlap": 120,
                        "scoring": "+1/-1/-1/-1", "reads": len(reads), "bases": int(offs[-1]),
                        "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles,

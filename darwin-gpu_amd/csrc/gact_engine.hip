@@ -120,6 +120,8 @@ struct gact_hip_engine {
     int C = 20;                 // columns per lane
     bool p16 = false;           // scoring fits the packed-int16 main kernel
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
+    bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
+    int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
     gact::P16Consts kc;
     hipDeviceProp_t prop;
     int grid_blocks = 0;        // persistent grid
@@ -241,9 +243,16 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     const int seed_waves = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
     const int seed_blocks = std::max(1, std::min((seed_waves + 3) / 4, e->grid_blocks));
     const int main_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->grid_blocks));
-    hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
-                       e->kp, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from, same_file,
-                       sl.overlaps.p, queues(sl), e->p16 ? 1 : 0, sl.d_ws);
+    if (e->seed16) {
+        const int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
+        hipLaunchKernelGGL((gact::seed_p16_kernel<C>), dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
+                           e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
+                           same_file, sl.overlaps.p, queues(sl), sl.d_ws);
+    } else {
+        hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
+                           e->kp, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from, same_file,
+                           sl.overlaps.p, queues(sl), e->p16 ? 1 : 0, sl.d_ws);
+    }
     HIP_TRY(hipGetLastError());
     sl.two_phase = e->p16;
     if (e->p16) {
@@ -271,6 +280,14 @@ template <int C> int occupancy_blocks(int *out)
     int d = c;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, gact::extend_p16_kernel<gact::SplitLayout<7, 13>>, gact::kBlockThreads, 0));
     *out = std::max(1, std::min(std::min(a, b), std::min(c, d)));
+    return 0;
+}
+
+template <int C> int seed_occupancy_blocks(int *out)
+{
+    int a = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::seed_p16_kernel<C>, gact::kBlockThreads, 0));
+    *out = std::max(1, a);
     return 0;
 }
 
@@ -368,6 +385,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
              getenv("GACT_HIP_FORCE_INT32") == nullptr;
     e->split = e->p16 && e->C == 20 && e->kp.early <= gact::GeometrySplit<7, 13>::W2 &&
                getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
+    e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     static_assert(gact::GeometrySplit<7, 13>::kWsWords <= gact::Geometry<20>::kWsWords, "workspace too small");
     e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);
     e->kc.open = gact::pk2(p->gap_open); e->kc.ext = gact::pk2(p->gap_extend);
@@ -376,6 +394,13 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     rc = (e->C == 20) ? occupancy_blocks<20>(&e->blocks_per_cu) : occupancy_blocks<32>(&e->blocks_per_cu);
     if (rc) { delete e; return rc; }
     e->grid_blocks = e->blocks_per_cu * e->prop.multiProcessorCount;
+    {
+        int sb = 0;
+        rc = (e->C == 20) ? seed_occupancy_blocks<20>(&sb) : seed_occupancy_blocks<32>(&sb);
+        if (rc) { delete e; return rc; }
+        // the workspace is sized for grid_blocks groups
+        e->seed_grid_blocks = std::min(sb * e->prop.multiProcessorCount, e->grid_blocks);
+    }
     const size_t groups = (size_t)e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
     e->ws_words_total = groups * gact::kSlots * (size_t)e->kp.ws_words;    // two tiles per group in the p16 kernel
 
@@ -622,6 +647,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
     st->main_ms = st->total_ms;
     st->packed16 = sl.two_phase ? (e->split ? 2 : 1) : 0;
+    st->seed_packed16 = (sl.two_phase && e->seed16) ? 1 : 0;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
         HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));

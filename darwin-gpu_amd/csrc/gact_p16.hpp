@@ -119,6 +119,26 @@ __device__ __forceinline__ uint32_t pk_shl_add4(uint32_t acc, uint32_t code)   /
     return r;
 }
 
+__device__ __forceinline__ uint32_t pk_mad8(uint32_t a, uint32_t c)              // a*8 + c (signed halves)
+{
+    uint32_t r;
+    asm("v_pk_mad_i16 %0, %1, 8, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad_m1(uint32_t a, uint32_t b)             // a*b - 1 (wrapping halves)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, -1 op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// arg-max of the packed pass (first tiles): the key H*8 + (step & 7) must stay under 2^14, so that a
+// row outside the tile can be keyed negative by a -2^14 bias
+constexpr int kKeyBias = -16384;
+__host__ inline bool p16_argmax_ok(int tile, int match) { return (long long)match * (tile + 2) * 8 + 7 < 16384; }
+
+struct P16Best { int best[2], bi[2], bj[2]; };
+
 template <int C> struct GeometryP16 {
     static constexpr int kTileMax = C * kGroup;
     static constexpr int kMaxSteps = kTileMax + kGroup;
@@ -133,12 +153,18 @@ template <int C> struct GeometryP16 {
 // One pass of a wave: 4 groups x 2 tiles.  ref16 is this lane's view of the
 // group's ref stream: entry [t] holds the bases of step-row (t - gl) of both
 // tiles (each tile's own start delay is folded in when the stream is written).
-template <int C>
+//
+// AMAX (first tiles, align.cpp:173-177): every column slot keeps the largest key H*8 + (step & 7) of the
+// current 8-step block (a later row wins a tie; rows outside 1..R are keyed negative); at every flush the
+// slots of a lane are folded in column order (a later column wins a tie, columns past Q masked) into one
+// 32-bit (H, step, column) record per tile, and the 16 lanes are merged at the end.
+template <int C, bool AMAX = false>
 __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                                             const uint16_t *__restrict__ ref16,
                                             const uint32_t (&qb)[C],
                                             const int T_end, const int tB,
-                                            uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB)
+                                            uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
+                                            const int (*RQ)[2] = nullptr, P16Best *pb = nullptr)
 {
     uint32_t Hm[C], Mo[C], Iup[C];          // H+match, M+open, I of the previous row (both tiles)
     // Pointer bits, packed for both tiles (tile A low half-word, tile B high), 8 rows per half-word:
@@ -156,12 +182,33 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
     uint32_t Mo_last = kc.open, D_last = kc.ninf, Hm_last = kc.match;
     uint32_t Hm_left_prev = kc.match;
 
+    // arg-max state (AMAX only; RQ[h] = {R, Q} of tile h, no start delay: first tiles store from step 1)
+    uint32_t bk[AMAX ? C : 1];
+    int lane_best[2] = {-1, -1};
+    uint32_t col_x0 = 0;                     // packed (0 - valid columns of this lane)
+    int t_first = 0, rows[2] = {0, 0};
+    if (AMAX) {
+#pragma unroll
+        for (int c = 0; c < C; c++) bk[c] = 0xffffffffu;
+        const int ncA = imin(imax(RQ[0][1] - gl * C, 0), C), ncB = imin(imax(RQ[1][1] - gl * C, 0), C);
+        col_x0 = ((uint32_t)(-ncA) & 0xffffu) | ((uint32_t)(-ncB) << 16);
+        t_first = gl + 1;
+        rows[0] = RQ[0][0]; rows[1] = RQ[1][0];
+    }
+
     auto unpack = [](uint32_t w) { return (w & 0xffu) | ((w & 0xff00u) << 8); };
     uint32_t rbp = unpack(ref16[1]);
 
     auto step = [&](const int t, auto ptr_tag) {
         constexpr bool PTR = decltype(ptr_tag)::value;
         const uint32_t w_next = ref16[t + 1];
+        uint32_t key_c = 0;
+        if (AMAX) {
+            const uint32_t sidx = (uint32_t)(t - tB) & 7u, row0 = (uint32_t)(t - t_first);
+            const uint32_t ka = row0 < (uint32_t)rows[0] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
+            const uint32_t kb = row0 < (uint32_t)rows[1] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
+            key_c = ka | (kb << 16);
+        }
 
         const uint32_t Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)kc.open);
         const uint32_t Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)kc.ninf);
@@ -197,6 +244,7 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                 const uint32_t o = pk_mad_vvv(na, nb, na);          // 0 MATCH, 1 INSERT, 2 DELETE
                 accO[c] = pk_shl_add4(accO[c], pk_mad_vvv(nz, o, nz));
             }
+            if (AMAX) bk[c] = pk_max(bk[c], pk_mad8(H, key_c));
             Hm[c] = pk_add_s(H, kc.match);
             Ml = Mo[c];
             Dl = D;
@@ -210,6 +258,28 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
     // tile A's word = {accF.lo, accO.lo}, tile B's = {accF.hi, accO.hi}: flags in the high half-word
     auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
     auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
+
+    // fold the block keys of stored steps kblk..kblk+7 into lane_best
+    auto fold = [&](const int kblk) {
+        uint32_t m = 0xffffffffu, rel = 0, x = col_x0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t v = pk_sign(x);                              // column c exists in this tile
+            x = pk_add(x, kc.one);
+            const uint32_t key = pk_mad_m1(v, pk_add(bk[c], kc.one));   // v ? key : -1
+            const uint32_t keep = pk_sign(pk_sub(key, m));              // key < m: the earlier column stays
+            rel = pk_mad_m1(keep, rel);                                 // (best column) - (next c)
+            m = pk_max(m, key);
+            bk[c] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int m16 = (int)(m << (16 - 16 * h)) >> 16;
+            const int col = ((int)(rel << (16 - 16 * h)) >> 16) + C;
+            const int rec = ((m16 >> 3) << 15) | ((kblk + (m16 & 7)) << 5) | col;    // 11 + 10 + 5 bits
+            lane_best[h] = imax(lane_best[h], m16 < 0 ? -1 : rec);
+        }
+    };
 
     int t = 1;
     for (; t < tB && t <= T_end; t++) step(t, std::false_type{});
@@ -228,6 +298,32 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
             }
             qA += (C / 4) * kGroup;
             qB += (C / 4) * kGroup;
+            if (AMAX) fold(k - 7);
+        }
+    }
+    if (AMAX) {
+        if (k & 7) fold(k & ~7);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int rec = lane_best[h];
+            int best = 0, bi = 0, bj = 0;                               // align.cpp:109-112
+            if (rec >= 0) {
+                best = rec >> 15;
+                bi = tB + ((rec >> 5) & 1023) - gl;
+                bj = gl * C + (rec & 31) + 1;
+            }
+            // merge the 16 lanes: largest H, then largest i, then largest j
+#pragma unroll
+            for (int mm = 1; mm < kGroup; mm <<= 1) {
+                const int ob = __shfl_xor(best, mm, kGroup);
+                const int oi = __shfl_xor(bi, mm, kGroup);
+                const int oj = __shfl_xor(bj, mm, kGroup);
+                const bool take = (ob > best) | ((ob == best) & ((oi > bi) | ((oi == bi) & (oj > bj))));
+                best = take ? ob : best;
+                bi = take ? oi : bi;
+                bj = take ? oj : bj;
+            }
+            pb->best[h] = best; pb->bi[h] = bi; pb->bj[h] = bj;
         }
     }
     if (k & 7) {
@@ -487,6 +583,145 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
     if ((threadIdx.x & 63) == 0)
         for (int k = 0; k < 8; k++) atomicAdd(&g_stamps[k], stamp_acc[k]);
 #endif
+}
+
+// ---------------------------------------------------------------------------
+// Packed seed launch: the first tile(s) of every candidate (arg-max, pointers of the
+// whole tile), two candidates per group, then the chain is handed to the main launch
+// (ChainQueues) exactly as the int32 seed launch does (extend_kernel, seed_mode).
+// Needs p16_argmax_ok on top of p16_scoring_ok.
+template <int C>
+__global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
+    KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
+    const gact_candidate *__restrict__ cands, int first_cand, int n, int rc_from,
+    int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
+    uint32_t *__restrict__ ws_all)
+{
+    using L = UniformLayout<C>;
+    using G = typename L::G;
+    constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
+    __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
+
+    const WaveCtx w = wave_ctx();
+    const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
+    uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
+    uint8_t *q8 = ref8 + G::kRefBytes;
+    const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (L::kRow0 - 1 - w.gl);
+    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
+    uint32_t *wsB = wsA + kp.ws_words;
+    const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
+
+    ChainState *st = chain_lds[group_in_block];
+    if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; st[w.gl].comp = 0; }
+    wave_sync();
+    bool exhausted = false;
+    __builtin_amdgcn_s_setprio(3);
+
+    for (;;) {
+        // ---- both slots pick their next first tile, finishing / fetching candidates on the way
+        PairTile pt;
+        bool have[kSlots];
+        int RQ[kSlots][2];
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            ChainState s = st[h];
+            TilePick pk;
+            pk.have = false; pk.R = 0; pk.Q = 0; pk.reverse = false; pk.rp0 = 0; pk.qp0 = 0;
+            for (int guard = 0; guard < 3 && !pk.have; guard++) {
+                if (s.phase == 2) {
+                    if (exhausted) break;
+                    int idx = 0;
+                    if (w.gl == 0) idx = atomicAdd(cq.pop_seed, 1);
+                    idx = __shfl(idx, 0, kGroup);
+                    if (idx >= n) { exhausted = true; break; }
+                    chain_begin(s, first_cand + idx, cands[first_cand + idx], refs, qfwd, qrc, rc_from);
+                }
+                pk = chain_pick(s, kp, same_file, out, w.gl == 0);
+                if (!pk.have && w.gl == 0)
+                    atomicAdd(cq.seed_cells, (unsigned long long)s.cells);     // finished inside the seed launch
+            }
+            have[h] = pk.have;
+            pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
+            pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
+            RQ[h][0] = pk.R; RQ[h][1] = pk.Q;
+            wave_sync();
+            if (w.gl == 0) st[h] = s;
+            wave_sync();
+        }
+        if (!__any(have[0] | have[1])) {
+            if (__all(exhausted && st[0].phase == 2 && st[1].phase == 2)) break;
+            continue;
+        }
+        // first tiles store pointers from step 1 on, so nobody is delayed; the pass ends with the longest tile
+        const int T_end = wave_max4(imax(L::last_step(pt.R[0], pt.Q[0]), L::last_step(pt.R[1], pt.Q[1])));
+
+        uint32_t qb[C];
+        L::load(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
+        wave_sync();
+
+        P16Best pb;
+        __builtin_amdgcn_s_setprio(0);
+        dp_pass_p16<C, true>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, RQ, &pb);
+        __builtin_amdgcn_s_setprio(3);
+
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pointer stores -> L2 before the sc1 loads
+
+        // ---- first-tile bookkeeping (gact.cpp:99-110 / :162-171), group-uniform
+        bool stop[kSlots];
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            stop[h] = true;
+            if (have[h]) {
+                ChainState s = st[h];
+                s.n_tiles++;
+                s.cells += (int64_t)pt.R[h] * pt.Q[h];
+                stop[h] = chain_first_tile(s, kp, pt.R[h], pt.Q[h], pb.best[h], pb.bi[h], pb.bj[h]);
+                wave_sync();
+                if (w.gl == 0) st[h] = s;
+            }
+            wave_sync();
+        }
+        // ---- traceback from the arg-max: lane h of the group walks slot h
+        int ref_steps = 0, query_steps = 0, nst = 0;
+        ScoreWalk wk;
+        wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
+        {
+            const int h = w.gl & 1;
+            const bool mine = (w.gl < kSlots) && !(h ? stop[1] : stop[0]);
+            const ChainState &s = st[h];
+            wk.load(s);
+            if (mine) {
+                const int i0 = h ? pb.bi[1] : pb.bi[0], j0 = h ? pb.bj[1] : pb.bj[0];
+                const int l0 = (j0 - 1) / C;
+                walk_chain<C, 1, C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
+                                        i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
+                                        s.phase, kp, wk, ref_steps, query_steps, nst);
+            }
+        }
+        // ---- consume; a chain whose first tile is done belongs to the main launch
+#pragma unroll
+        for (int h = 0; h < kSlots; h++) {
+            if (have[h]) {
+                ChainState s = st[h];
+                chain_advance(s, stop[h], wk, ref_steps, query_steps, nst, h);
+                if (!s.first_tile) {
+                    if (w.gl == 0) {
+                        cq.states[s.cand] = s;
+                        const int b = chain_bucket(s, kp);
+                        const int slot = atomicAdd(&cq.bucket_count[b], 1);
+                        cq.live[(size_t)b * cq.live_stride + slot] = s.cand;
+                        atomicAdd(cq.seed_cells, (unsigned long long)s.cells);
+                    }
+                    s.phase = 2;
+                }
+                wave_sync();
+                if (w.gl == 0) st[h] = s;
+            }
+            wave_sync();
+        }
+    }
 }
 
 }  // namespace gact

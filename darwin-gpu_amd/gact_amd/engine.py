@@ -44,7 +44,8 @@ class DeviceInfo(C.Structure):
 
 class RunStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("seed_ms", C.c_float), ("main_ms", C.c_float),
-                ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_cells", C.c_int64)]
+                ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_packed16", C.c_int32),
+                ("reserved", C.c_int32), ("seed_cells", C.c_int64)]
 
 
 class GactHipError(RuntimeError):
@@ -265,6 +266,7 @@ class Engine:
         self._check(self.L.gact_hip_last_run_stats(self.h, slot, C.byref(st)))
         return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
                 "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split")[st.packed16],
+                "seed_layout": "packed16" if st.seed_packed16 else "int32",
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells}
 
     def measure_valu_rate(self):

@@ -193,14 +193,16 @@ int gact_hip_sync(gact_hip_engine *e, int slot);
 /* HIP-event time of the last kernel launched on this slot's stream, in ms */
 int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);
 /* How the last candidates_run* on this slot was executed.  With the default
- * scoring the chain runs as two launches: a seed launch (int32 kernel, first
- * tile of every candidate, arg-max + full pointer matrix) and the main launch
- * (packed-int16 kernel, every later tile). */
+ * scoring the chain runs as two launches: a seed launch (first tile of every
+ * candidate, arg-max + full pointer matrix) and the main launch (packed-int16
+ * kernel, every later tile). */
 typedef struct {
     float total_ms, seed_ms, main_ms;   /* HIP events on the slot's stream */
     int32_t packed16;                   /* 0: one int32 launch; 1: seed + packed-int16 main launch, uniform
                                            column layout; 2: the same, split (two-region) layout */
     int32_t handed_off;                 /* candidates the main launch continued */
+    int32_t seed_packed16;              /* 1: the seed launch ran the packed-int16 arg-max kernel, 0: the int32 one */
+    int32_t reserved;
     int64_t seed_cells;                 /* DP cells executed by the seed launch */
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);

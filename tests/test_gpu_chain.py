@@ -38,16 +38,19 @@ def _run(rs, cf, cr, oracle, scoring=(1, -1, -1, -1), tile=320, overlap=120, thr
     return total
 
 
-@pytest.fixture(params=["packed16", "packed16-uniform", "int32"], autouse=True)
+@pytest.fixture(params=["packed16", "packed16-uniform", "int32-seed", "int32"], autouse=True)
 def kernel_family(request, monkeypatch):
-    """every chain test runs three times: seed + packed-int16 main launch in its split layout (default where
-    the geometry allows it), the same in the uniform layout, and the int32 kernel alone"""
-    monkeypatch.delenv("GACT_HIP_FORCE_INT32", raising=False)
-    monkeypatch.delenv("GACT_HIP_FORCE_UNIFORM", raising=False)
+    """every chain test runs four times: packed seed + packed main launch in its split layout (default where
+    the geometry allows it), the same in the uniform layout, the int32 seed launch in front of the packed main
+    launch, and the int32 kernel alone"""
+    for var in ("GACT_HIP_FORCE_INT32", "GACT_HIP_FORCE_UNIFORM", "GACT_HIP_FORCE_INT32_SEED"):
+        monkeypatch.delenv(var, raising=False)
     if request.param == "int32":
         monkeypatch.setenv("GACT_HIP_FORCE_INT32", "1")
     elif request.param == "packed16-uniform":
         monkeypatch.setenv("GACT_HIP_FORCE_UNIFORM", "1")
+    elif request.param == "int32-seed":
+        monkeypatch.setenv("GACT_HIP_FORCE_INT32_SEED", "1")
     return request.param
 
 
@@ -60,7 +63,9 @@ def test_kernel_family_is_the_one_asked_for(kernel_family):
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
     eng.extend(cf)
     st = eng.last_run_stats()
-    assert st["layout"] == {"packed16": "packed16-split", "packed16-uniform": "packed16-uniform", "int32": "int32"}[kernel_family]
+    assert st["layout"] == {"packed16": "packed16-split", "packed16-uniform": "packed16-uniform",
+                            "int32-seed": "packed16-split", "int32": "int32"}[kernel_family]
+    assert st["seed_layout"] == ("packed16" if kernel_family.startswith("packed16") else "int32")
     if st["packed16"]:
         assert 0 < st["handed_off"] <= len(cf) and st["seed_cells"] > 0
     eng.close()
@@ -69,6 +74,13 @@ def test_kernel_family_is_the_one_asked_for(kernel_family):
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
     eng.extend(cf)
     assert eng.last_run_stats()["packed16"] is False
+    eng.close()
+    # arg-max keys of the packed seed kernel need match*(tile+2)*8 < 2^14: beyond that only the seed falls back
+    eng = engine.Engine(scoring=(8, -8, -10, -4))
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
+    eng.extend(cf)
+    st = eng.last_run_stats()
+    assert st["seed_layout"] == "int32" and st["packed16"] == (kernel_family != "int32")
     eng.close()
 
 
@@ -79,7 +91,8 @@ def test_chain_small(oracle):
     assert _run(rs, cf, cr, oracle) > 100
 
 
-@pytest.mark.parametrize("scoring", [(2, -3, -5, -2), (5, -4, -10, -1), (1, -1, -2, -1), (30, -40, -70, -20)])
+@pytest.mark.parametrize("scoring", [(2, -3, -5, -2), (5, -4, -10, -1), (1, -1, -2, -1), (30, -40, -70, -20),
+                                     (6, -4, 0, 0), (3, 0, -2, 0)])
 def test_chain_other_scoring(oracle, scoring):
     from gact_amd import synth
     rs = synth.simulate_reads(20000, n_reads=16, seed=8, mean_len=4000, sd_len=1000, min_len=800, max_len=8000)

@@ -264,13 +264,18 @@ struct ChainQueues {
     ChainState *states;          // their chain states
 };
 
-// tiles this chain still has to run, roughly (each tile advances ~early bases)
+// bases this chain still has to cover, roughly (each tile advances ~early of them)
+__device__ __forceinline__ int chain_remaining(const ChainState &s)
+{
+    if (s.phase == 0)
+        return imax(0, imin(s.ref_pos, s.query_pos)) +
+               imax(0, imin(s.ref_len - s.rev_ref_pos, s.query_len - s.rev_query_pos));
+    return imax(0, imin(s.ref_len - s.ref_pos, s.query_len - s.query_pos));
+}
+
 __device__ __forceinline__ int chain_bucket(const ChainState &s, const KParams &kp)
 {
-    int bases = imax(0, imin(s.ref_len - s.ref_pos, s.query_len - s.query_pos));
-    if (s.phase == 0) bases = imax(0, imin(s.ref_pos, s.query_pos)) +
-                              imax(0, imin(s.ref_len - s.rev_ref_pos, s.query_len - s.rev_query_pos));
-    const int tiles = bases / imax(kp.early, 1);
+    const int tiles = chain_remaining(s) / imax(kp.early, 1);
     return imax(0, kBuckets - 1 - tiles / kBucketTiles);
 }
 

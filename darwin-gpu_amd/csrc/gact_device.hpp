@@ -48,6 +48,7 @@ struct KParams {
     int32_t match, mismatch, open, ext;
     int32_t thr;
     int32_t ws_words;         // workspace dwords per group
+    int32_t prio_bases[2];    // main launch: chains with more bases left than this run their DP at priority 1 / 2
 };
 
 template <int C> struct Geometry {

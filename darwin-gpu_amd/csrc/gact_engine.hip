@@ -52,6 +52,7 @@ struct SeqSet {
     std::vector<int64_t> h_offsets;
     int32_t n = 0;
     int64_t total = 0;
+    int64_t max_len = 0;      // longest sequence of the set
     bool has_other = false;   // holds bytes other than A/C/G/T
     size_t cap_bases = 0, cap_seqs = 0;
 
@@ -120,6 +121,7 @@ struct gact_hip_engine {
     int C = 20;                 // columns per lane
     bool p16 = false;           // scoring fits the packed-int16 main kernel
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
+    bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
     gact::P16Consts kc;
@@ -178,6 +180,8 @@ int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, c
     s.h_offsets.assign(offsets, offsets + n_seqs + 1);
     if (n_seqs == 0) s.h_offsets.assign(1, 0);
     s.n = n_seqs; s.total = total;
+    s.max_len = 0;
+    for (int32_t k = 0; k < n_seqs; k++) s.max_len = std::max(s.max_len, offsets[k + 1] - offsets[k]);
 
     HIP_TRY(hipMemcpyAsync(s.d_offsets, s.h_offsets.data(), s.h_offsets.size() * sizeof(int64_t),
                            hipMemcpyHostToDevice, sl.stream));
@@ -243,14 +247,19 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     const int seed_waves = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
     const int seed_blocks = std::max(1, std::min((seed_waves + 3) / 4, e->grid_blocks));
     const int main_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->grid_blocks));
+    // DP issue priority by remaining chain length (extend_p16_kernel): thirds of the longest possible chain
+    gact::KParams kp = e->kp;
+    const int64_t longest = std::min(rs.max_len, std::max(need_f ? qf.max_len : 0, need_r ? qr.max_len : 0));
+    kp.prio_bases[0] = e->chain_prio ? (int32_t)std::min<int64_t>(longest / 3, 0x7fffffff) : 0x7fffffff;
+    kp.prio_bases[1] = e->chain_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : 0x7fffffff;
     if (e->seed16) {
         const int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
         hipLaunchKernelGGL((gact::seed_p16_kernel<C>), dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
-                           e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
+                           kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
                            same_file, sl.overlaps.p, queues(sl), sl.d_ws);
     } else {
         hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
-                           e->kp, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from, same_file,
+                           kp, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from, same_file,
                            sl.overlaps.p, queues(sl), e->p16 ? 1 : 0, sl.d_ws);
     }
     HIP_TRY(hipGetLastError());
@@ -259,11 +268,11 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
         if (e->split)
             hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayout<7, 13>>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
-                               sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
+                               sl.stream, kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
                                same_file, sl.overlaps.p, queues(sl), sl.d_ws);
         else
             hipLaunchKernelGGL((gact::extend_p16_kernel<gact::UniformLayout<C>>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
-                               sl.stream, e->kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
+                               sl.stream, kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
                                same_file, sl.overlaps.p, queues(sl), sl.d_ws);
         HIP_TRY(hipGetLastError());
     }
@@ -386,6 +395,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->split = e->p16 && e->C == 20 && e->kp.early <= gact::GeometrySplit<7, 13>::W2 &&
                getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
+    e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
+    e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;
     static_assert(gact::GeometrySplit<7, 13>::kWsWords <= gact::Geometry<20>::kWsWords, "workspace too small");
     e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);
     e->kc.open = gact::pk2(p->gap_open); e->kc.ext = gact::pk2(p->gap_extend);

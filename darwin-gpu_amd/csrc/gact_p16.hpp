@@ -474,6 +474,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
         PairTile pt;
         bool have[kSlots];
         int Tend_h[kSlots], tB_h[kSlots];
+        int longest = 0;             // bases the longest chain of this group still has to cover
 #pragma unroll
         for (int h = 0; h < kSlots; h++) {
             ChainState s = st[h];
@@ -501,6 +502,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
             have[h] = pk.have;
             pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
             pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
+            if (pk.have) longest = imax(longest, chain_remaining(s));
             Tend_h[h] = L::last_step(pk.R, pk.Q);
             tB_h[h] = L::first_pointer_step(pk.R, pk.Q, kp.early);
             wave_sync();
@@ -529,7 +531,12 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
         // the DP pass is throughput work; everything else in this loop is a short serial
         // chain (traceback, chain bookkeeping, loads) that must not queue behind other
         // waves' DP instructions: run it at raised issue priority
-        __builtin_amdgcn_s_setprio(0);
+        // ... and among the DP passes, the waves that carry the longest chains go first: when there are
+        // fewer chains than tile slots the launch lasts as long as its longest chain
+        const int wave_longest = wave_max4(longest);
+        if (wave_longest > kp.prio_bases[1]) __builtin_amdgcn_s_setprio(2);
+        else if (wave_longest > kp.prio_bases[0]) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
         L::pass(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
         __builtin_amdgcn_s_setprio(3);
         GACT_STAMP(t_d);

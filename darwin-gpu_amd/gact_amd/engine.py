@@ -13,7 +13,8 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # darwin-gp
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp")] + \
+           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp",
+            "dsoft_device.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
 SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2
@@ -46,6 +47,23 @@ class RunStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("seed_ms", C.c_float), ("main_ms", C.c_float),
                 ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_packed16", C.c_int32),
                 ("reserved", C.c_int32), ("seed_cells", C.c_int64)]
+
+
+class DsoftParams(C.Structure):
+    """params.cfg [DSOFT_params]; the defaults are the reference's"""
+    _fields_ = [(n, C.c_int32) for n in ("seed_size", "bin_size", "window_size", "threshold", "num_seeds",
+                                         "seed_occurence_multiple", "max_candidates")]
+
+    def __init__(self, seed_size=14, bin_size=64, window_size=4, threshold=21, num_seeds=800,
+                 seed_occurence_multiple=32, max_candidates=1000000):
+        super().__init__(seed_size, bin_size, window_size, threshold, num_seeds, seed_occurence_multiple,
+                         max_candidates)
+
+
+class DsoftInfo(C.Structure):
+    _fields_ = [("ref_length", C.c_int64), ("n_minimizers", C.c_int64), ("table_bytes", C.c_int64),
+                ("pos_bytes", C.c_int64), ("max_occurrence", C.c_int32), ("n_bins", C.c_int32),
+                ("build_ms", C.c_float)]
 
 
 class GactHipError(RuntimeError):
@@ -131,7 +149,10 @@ def load():
     L.gact_hip_measure_valu_rate.argtypes = [vp, C.POINTER(C.c_double)]
     L.gact_hip_measure_valu_rate.restype = C.c_int
     L.gact_hip_format_overlap.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_char_p, i32]
-    for name in ("create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
+    L.gact_hip_dsoft_build.argtypes = [vp, C.POINTER(DsoftParams), C.POINTER(DsoftInfo)]
+    L.gact_hip_dsoft_query.argtypes = [vp, C.c_int, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
+    L.gact_hip_candidates_download.argtypes = [vp, C.c_int, i32, vp]
+    for name in ("dsoft_build", "dsoft_query", "candidates_download", "create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
                  "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range", "candidates_run_mixed",
                  "candidates_fetch", "sync", "last_kernel_ms", "last_run_stats", "format_overlap"):
         getattr(L, "gact_hip_" + name).restype = C.c_int
@@ -144,7 +165,8 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_extend_candidates", "gact_hip_candidates_upload", "gact_hip_candidates_run",
            "gact_hip_candidates_run_range", "gact_hip_candidates_run_mixed", "gact_hip_candidates_fetch", "gact_hip_sync",
            "gact_hip_last_kernel_ms", "gact_hip_last_run_stats", "gact_hip_device_overlaps", "gact_hip_stream",
-           "gact_hip_measure_valu_rate", "gact_hip_format_overlap")
+           "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
+           "gact_hip_candidates_download")
 
 
 class Engine:
@@ -255,6 +277,27 @@ class Engine:
 
     def sync(self, slot=0):
         self._check(self.L.gact_hip_sync(self.h, slot))
+
+    # ---- D-SOFT on the device
+    def dsoft_build(self, params=None):
+        """minimizer index over the uploaded SET_REF (seed_pos_table.cpp:46-98)"""
+        params = params or DsoftParams()
+        info = DsoftInfo()
+        self._check(self.L.gact_hip_dsoft_build(self.h, C.byref(params), C.byref(info)))
+        return {n: getattr(info, n) for n, _ in DsoftInfo._fields_}
+
+    def dsoft_query(self, first_query, n_queries, slot=0):
+        """filters queries [first, first+n) of SET_QUERY / SET_QUERY_RC; the slot's device candidate array then
+        holds the forward candidates followed by the reverse-complement ones.  Returns (n_forward, n_reverse, ms)."""
+        nf, nr, ms = C.c_int32(), C.c_int32(), C.c_float()
+        self._check(self.L.gact_hip_dsoft_query(self.h, slot, first_query, n_queries, C.byref(nf), C.byref(nr),
+                                                C.byref(ms)))
+        return nf.value, nr.value, float(ms.value)
+
+    def candidates_download(self, n, slot=0):
+        out = np.zeros(n, dtype=CAND_DTYPE)
+        self._check(self.L.gact_hip_candidates_download(self.h, slot, n, out.ctypes.data))
+        return out
 
     def last_kernel_ms(self, slot=0):
         ms = C.c_float()

@@ -189,6 +189,47 @@ int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, i
 int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, int32_t n,
                                   int32_t rc_from, int same_file);
 
+/* ------------------------------------------------------------------------
+ * D-SOFT seed filter on the device (the stage in front of the path; optional:
+ * the reference's host filter keeps working against the calls above).
+ *
+ * gact_hip_dsoft_build stands where darwin.cpp:532-560 builds the padded
+ * reference string and `new SeedPosTable(...)` (seed_pos_table.cpp:46-98): the
+ * index is built over GACT_SET_REF as uploaded (ASCII bases; anything but
+ * acgtACGT counts as A, ntcoding.cpp:59-71).
+ * gact_hip_dsoft_query stands where AlignReads calls sa->DSOFT for every read
+ * and its reverse complement and decodes the hits (darwin.cpp:209-224,252-263):
+ * queries [first_query, first_query + n_queries) of GACT_SET_QUERY / _RC are
+ * filtered and the slot's candidate array is filled ON THE DEVICE, all forward
+ * candidates first (query order, then emission order, as the reference's
+ * GACT_calls_for), then the reverse-complement ones; run them with
+ * gact_hip_candidates_run_mixed(e, slot, 0, *n_forward + *n_reverse, *n_forward, same_file).
+ */
+typedef struct {
+    int32_t seed_size;                 /* params.cfg DSOFT_params.seed_size, 4..15 */
+    int32_t bin_size;
+    int32_t window_size;               /* < seed_size */
+    int32_t threshold;
+    int32_t num_seeds;
+    int32_t seed_occurence_multiple;
+    int32_t max_candidates;            /* per query strand; must not bind (>= (num_seeds+1) * occurrence cap) */
+} gact_dsoft_params;
+
+typedef struct {
+    int64_t ref_length;                /* padded concatenation, darwin.cpp:544 */
+    int64_t n_minimizers;
+    int64_t table_bytes, pos_bytes;
+    int32_t max_occurrence;            /* kmer_max_occurence_, seed_pos_table.cpp:59 */
+    int32_t n_bins;
+    float build_ms;                    /* HIP events, all build kernels */
+} gact_dsoft_info;
+
+int gact_hip_dsoft_build(gact_hip_engine *e, const gact_dsoft_params *p, gact_dsoft_info *info);
+int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int32_t n_queries,
+                         int32_t *n_forward, int32_t *n_reverse, float *query_ms);
+/* copies candidates [0, n) of the slot's device array to the host */
+int gact_hip_candidates_download(gact_hip_engine *e, int slot, int32_t n, gact_candidate *out);
+
 int gact_hip_sync(gact_hip_engine *e, int slot);
 /* HIP-event time of the last kernel launched on this slot's stream, in ms */
 int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);

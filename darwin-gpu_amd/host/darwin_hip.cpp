@@ -1,7 +1,7 @@
 // darwin_hip.cpp -- a darwin.cpp-shaped driver around the GACT shim.
 //
 //   darwin_hip <REF.fasta> <READS.fasta> CPU_THREADS [--params params.cfg]
-//              [--candidates FILE | --dump-candidates FILE [--dsoft-only]]
+//              [--candidates FILE | --dump-candidates FILE [--dsoft-only]] [--device-dsoft]
 //
 // Plays the part of reference darwin.cpp:451-646 for the GACT stage: owns the
 // globals gact.cpp reads, loads params.cfg and the two FASTA files, builds the
@@ -14,6 +14,8 @@
 // forward strand, then reverse complement) or, with --candidates, from FILE: int32
 // records {ref_id, query_id, ref_pos, query_pos, comp}.  --dump-candidates writes the
 // same format; --dsoft-only stops after the filter (no GPU is touched).
+// --device-dsoft runs the filter on the GPU as well (gact_hip_dsoft_build / _query): every feeder thread
+// filters its read range straight into its slot's device candidate array and extends it from there.
 //
 //   darwin_hip --selftest FILE   exercises AlignWithBT / Align_Batch_GPU / GACT
 //                                on the cases in FILE and prints what they return.
@@ -32,6 +34,7 @@
 #include "align.h"
 #include "dsoft.h"
 #include "gact.h"
+#include "gact_hip.h"
 
 // ---- the globals of darwin.cpp:39-93 that gact.cpp / the shim read
 bool same_file = false;
@@ -137,6 +140,48 @@ static void feeder(int cpu_id, const std::vector<Cand> *all, size_t lo, size_t h
     fout.close();
 }
 
+// --device-dsoft: reads [lo, hi) are filtered and extended on the device, slot s.slot
+static void device_feeder(int cpu_id, int lo, int hi, GPU_storage s, std::vector<Cand> *dump)
+{
+    gact_hip_engine *e = (gact_hip_engine *)s.engine;
+    std::ofstream fout("darwin." + std::to_string(cpu_id) + ".out");
+    int32_t nf = 0, nr = 0;
+    float ms = 0;
+    auto check = [](int rc, const char *what) {
+        if (rc != 0) { printf("\n%s failed: %s\n\n", what, gact_hip_last_error()); exit(-1); }
+    };
+    check(gact_hip_dsoft_query(e, s.slot, lo, hi - lo, &nf, &nr, &ms), "gact_hip_dsoft_query");
+    const int32_t n = nf + nr;
+    if (dump) {
+        std::vector<gact_candidate> c((size_t)n);
+        check(gact_hip_candidates_download(e, s.slot, n, c.data()), "gact_hip_candidates_download");
+        for (int32_t k = 0; k < n; k++) dump->push_back(Cand{c[k].ref_id, c[k].query_id, c[k].ref_pos, c[k].query_pos, k >= nf});
+        return;
+    }
+    std::vector<gact_overlap> o((size_t)n);
+    check(gact_hip_candidates_run_mixed(e, s.slot, 0, n, nf, same_file), "gact_hip_candidates_run_mixed");
+    check(gact_hip_candidates_fetch(e, s.slot, n, o.data()), "gact_hip_candidates_fetch");
+    char line[1024];
+    for (const gact_overlap &r : o) {
+        if (!r.emitted) continue;
+        const int len = gact_hip_format_overlap(&r, reference_descrips[r.ref_id][0].c_str(),
+                                                reads_descrips[r.query_id][0].c_str(), line, sizeof line);
+        fout.write(line, len);
+    }
+}
+
+static void upload_set(gact_hip_engine *e, int which, const std::vector<std::string> &seqs)
+{
+    std::vector<int64_t> offs(seqs.size() + 1, 0);
+    for (size_t k = 0; k < seqs.size(); k++) offs[k + 1] = offs[k] + (int64_t)seqs[k].size();
+    std::vector<uint8_t> cat((size_t)offs.back());
+    for (size_t k = 0; k < seqs.size(); k++) memcpy(cat.data() + offs[k], seqs[k].data(), seqs[k].size());
+    if (gact_hip_upload_seqs(e, which, cat.data(), offs.data(), (int32_t)seqs.size()) != 0) {
+        printf("\nupload failed: %s\n\n", gact_hip_last_error());
+        exit(-1);
+    }
+}
+
 static void print_queue(const char *tag, std::queue<int> q)
 {
     printf("%s", tag);
@@ -212,12 +257,13 @@ int main(int argc, char *argv[])
         return 1;
     }
     std::string cand_path, dump_path, cfg_path = "params.cfg";
-    bool dsoft_only = false;
+    bool dsoft_only = false, device_dsoft = false;
     for (int a = 4; a < argc; a++) {
         if (!strcmp(argv[a], "--candidates") && a + 1 < argc) cand_path = argv[++a];
         else if (!strcmp(argv[a], "--dump-candidates") && a + 1 < argc) dump_path = argv[++a];
         else if (!strcmp(argv[a], "--params") && a + 1 < argc) cfg_path = argv[++a];
         else if (!strcmp(argv[a], "--dsoft-only")) dsoft_only = true;
+        else if (!strcmp(argv[a], "--device-dsoft")) device_dsoft = true;
     }
     std::map<std::string, double> cfg = parse_cfg(cfg_path);
     auto get = [&](const char *k, int dflt) { return cfg.count(k) ? (int)cfg[k] : dflt; };
@@ -243,6 +289,40 @@ int main(int argc, char *argv[])
     parse_fasta(reads_path, reads_descrips, reads_seqs, reads_lengths);
     for (const std::string &r : reads_seqs) rev_reads_seqs.push_back(rev_comp(r));
     std::cout << "Number of reads: " << reads_seqs.size() << std::endl;
+
+    if (device_dsoft) {
+        std::vector<GPU_storage> s;
+        GPU_init(tile_size, tile_overlap, gap_open, gap_extend, match_score, mismatch_score, tile_size - tile_overlap,
+                 &s, num_threads);
+        gact_hip_engine *e = (gact_hip_engine *)s[0].engine;
+        upload_set(e, GACT_SET_REF, reference_seqs);
+        upload_set(e, GACT_SET_QUERY, reads_seqs);
+        upload_set(e, GACT_SET_QUERY_RC, rev_reads_seqs);
+        gact_dsoft_params gp = {dp.seed_size, (int32_t)dp.bin_size, (int32_t)dp.window_size, dp.threshold, dp.num_seeds,
+                                (int32_t)dp.seed_occurence_multiple, dp.max_candidates};
+        gact_dsoft_info info;
+        if (gact_hip_dsoft_build(e, &gp, &info) != 0) { printf("\ndsoft_build failed: %s\n\n", gact_hip_last_error()); return 1; }
+        printf("Reference length: %lld, %zu pieces; device index: %lld minimizers, %.1f ms\n", (long long)info.ref_length,
+               reference_seqs.size(), (long long)info.n_minimizers, info.build_ms);
+        const int num_reads = (int)reads_seqs.size();
+        const int reads_per_thread = (int)std::ceil(1.0 * num_reads / num_threads);
+        std::vector<std::vector<Cand> > dumps(num_threads);
+        const bool dumping = !dump_path.empty() && dsoft_only;
+        std::vector<std::thread> threads;
+        for (int i = 0; i < num_threads; i++) {
+            const int lo = std::min(num_reads, i * reads_per_thread), hi = std::min(num_reads, lo + reads_per_thread);
+            threads.push_back(std::thread(device_feeder, i, lo, hi, s[i], dumping ? &dumps[i] : nullptr));
+        }
+        for (auto &t : threads) t.join();
+        if (dumping) {
+            std::ofstream out(dump_path, std::ios::binary);
+            size_t total = 0;
+            for (auto &v : dumps) { out.write((const char *)v.data(), (std::streamsize)(v.size() * sizeof(Cand))); total += v.size(); }
+            printf("num_candidates: %zu\n", total);
+        }
+        GPU_close(&s, num_threads);
+        return 0;
+    }
 
     // per-thread candidate lists, contiguous read ranges like darwin.cpp:619-629
     std::vector<std::vector<Cand> > per_thread(num_threads);

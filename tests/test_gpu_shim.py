@@ -117,9 +117,10 @@ def test_end_to_end_from_fasta_equals_reference_program(tmp_path):
     e2e = json.load(open(os.path.join(gold, "e2e.json")))
     (tmp_path / "reads.fasta").write_text(fasta)
     (tmp_path / "params.cfg").write_text(CFG % e2e["seed_size"])
-    for threads in (1, 3):
-        out = subprocess.run([_driver(), "reads.fasta", "reads.fasta", str(threads)], capture_output=True, text=True,
-                             cwd=tmp_path, timeout=300)
+    # host filter with 1 and 3 feeder threads, then the whole pipeline on the device (--device-dsoft)
+    for threads, extra in ((1, []), (3, []), (1, ["--device-dsoft"]), (3, ["--device-dsoft"])):
+        out = subprocess.run([_driver(), "reads.fasta", "reads.fasta", str(threads)] + extra, capture_output=True,
+                             text=True, cwd=tmp_path, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         got = []
         for t in range(threads):

@@ -40,6 +40,31 @@ def host_cores():
     return n
 
 
+def pmc_traffic(workload_name, candidates, kernel, cells):
+    """(bytes per launch, where from) of the dominant kernel from the newest committed PMC summary that was taken
+    on the same workload, candidate source, kernel and cell count; (None, None) otherwise.  WRITE_SIZE / FETCH_SIZE
+    are KiB; FETCH_SIZE is taken as reported (MI355X_MICROARCH.md: exact x2 for wide streaming reads, uncalibrated
+    for this kernel's 16-byte sc1 loads, so the read share is 1-2x the figure)."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    if workload_name != "ecoli10x" or candidates != "dsoft":
+        return None, None
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_round_end_ecoli10x.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if k.startswith("extend") and "WRITE_SIZE" in v)
+            rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if k.startswith("extend") and "FETCH_SIZE" in v)
+            b = d["write"]["_bench"]
+            if b["kernel"] != kernel or b["kernel_cells"] != cells:
+                continue
+            return int((wr + rd) * 1024), os.path.relpath(path, here) + \
+                " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes of this command; %.1f GB written + " \
+                "%.1f GB read as reported)" % (wr * 1024 / 1e9, rd * 1024 / 1e9)
+        except (OSError, KeyError, StopIteration, ValueError):
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,8 +179,14 @@ def main():
         seed_cells = int(kernel_ms[-1]["seed_cells"])
         main_cells = my_cells - seed_cells
         achieved_tops = OPS_PER_CELL * main_cells / (k_ms * 1e-3) / 1e12
+        main_kernel = {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
+                       "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>"}[kernel_ms[-1]["layout"]]
         measured_rate = eng.measure_valu_rate()
         peak_tops = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
+        # HBM bytes of the main launch cannot be counted from inside this process: they come from the separate
+        # rocprofv3 --pmc passes of this same command (scripts/gpu_pmc.sh), committed under profiles/; only used
+        # when they were taken on this workload and this kernel
+        traffic, traffic_source = pmc_traffic(args.workload, args.candidates, main_kernel, main_cells)
         roofline = {
             # integer-VALU roofline: algorithmic work = 24 int32 ops per DP cell
             # against the int32 issue rate.  The main kernel runs its score recurrence as packed int16
@@ -164,9 +195,8 @@ def main():
             "bound": "valu", "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 3),
             "unit": "TOP/s (int32-equivalent lane-ops, 24 per DP cell)", "frac": round(achieved_tops / peak_tops, 4),
             "frac_packed16": round(achieved_tops / (2 * peak_tops), 4),
-            "traffic": None,
-            "kernel": {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
-                       "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>"}[kernel_ms[-1]["layout"]],
+            "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": main_kernel,
             "kernel_ms": round(float(k_ms), 3),
             "kernel_cells": main_cells, "seed_kernel": {"packed16": "seed_p16_kernel<20>", "int32": "extend_kernel<20>"}[kernel_ms[-1]["seed_layout"]],
             "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,

@@ -25,13 +25,30 @@ def test_every_declared_symbol_is_exported(hip_lib_path):
     assert set(names) == set(engine.EXPORTS)
 
 
-def test_struct_layouts():
+def test_struct_layouts(tmp_path):
+    """sizes and a few offsets as a C compiler sees include/gact_hip.h == what the ctypes / numpy side declares"""
+    import subprocess
     from gact_amd import engine
     assert engine.TILE_DTYPE.itemsize == 28
     assert engine.TILE_RESULT_DTYPE.itemsize == 24
     assert engine.CAND_DTYPE.itemsize == 16
     assert engine.OVERLAP_DTYPE.itemsize == 56 and engine.OVERLAP_DTYPE.fields["cells"][1] == 48
     assert ctypes.sizeof(engine.Params) == 40
+    (tmp_path / "abi.c").write_text(
+        "#include <stdio.h>\n#include <stddef.h>\n#include \"gact_hip.h\"\n"
+        "int main(void) { printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(gact_hip_params), "
+        "sizeof(gact_tile), sizeof(gact_tile_result), sizeof(gact_candidate), sizeof(gact_overlap), "
+        "offsetof(gact_overlap, cells), sizeof(gact_hip_run_stats), offsetof(gact_hip_run_stats, seed_cells), "
+        "sizeof(gact_hip_device_info), sizeof(gact_dsoft_params), sizeof(gact_dsoft_info), "
+        "offsetof(gact_dsoft_info, build_ms)); return 0; }\n")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), "-o", str(tmp_path / "abi"),
+                           str(tmp_path / "abi.c")])
+    got = [int(v) for v in subprocess.check_output([str(tmp_path / "abi")]).split()]
+    want = [ctypes.sizeof(engine.Params), engine.TILE_DTYPE.itemsize, engine.TILE_RESULT_DTYPE.itemsize,
+            engine.CAND_DTYPE.itemsize, engine.OVERLAP_DTYPE.itemsize, engine.OVERLAP_DTYPE.fields["cells"][1],
+            ctypes.sizeof(engine.RunStats), engine.RunStats.seed_cells.offset, ctypes.sizeof(engine.DeviceInfo),
+            ctypes.sizeof(engine.DsoftParams), ctypes.sizeof(engine.DsoftInfo), engine.DsoftInfo.build_ms.offset]
+    assert got == want
 
 
 def test_create_fails_loudly_without_a_device(hip_lib_path):

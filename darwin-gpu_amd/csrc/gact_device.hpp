@@ -69,12 +69,15 @@ __device__ __forceinline__ int dpp_row_shr1(int v, int old)
 }
 
 // x*2 + bit(lane) in one VALU op: the lane mask of a compare is the carry-in
-// of v_addc_co_u32 (hipcc does not form this from `x + x + cond`)
+// of v_addc_co_u32 (hipcc does not form this from `x + x + cond`).  The mask may
+// have been written by the VALU instruction right in front (v_cmp); gfx940+ wants
+// two wait states between a VALU SGPR write and a VALU read of it, which the
+// compiler cannot place for an operand of inline asm, hence the s_nop.
 __device__ __forceinline__ uint32_t shl1_insert(uint32_t x, uint64_t lane_mask)
 {
     uint32_t r;
     uint64_t carry_out;
-    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(lane_mask));
+    asm("s_nop 1\n\tv_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(lane_mask));
     return r;
 }
 __device__ __forceinline__ uint64_t lanes(bool cond) { return __builtin_amdgcn_ballot_w64(cond); }

@@ -162,68 +162,96 @@ struct ScoreWalk {
 
 // The chain kernels' walker: traceback (align.cpp:185-230) fused with the rescoring
 // of gact.cpp:197-210, written for few instructions per step -- every step of a
-// walker is a whole wave instruction however few lanes walk.  Lane / column /
-// stored-step of the current cell are tracked incrementally (no division), the
-// column bookkeeping is branch-free, pointer words come from the region cache.
-// rrow/qrow point at the LDS byte of DP row 1 / column 1; rstride is the ref
-// stream's byte stride.
-// (l, c, k) = lane, column-in-lane and stored step of the start cell (R, Q) in the pass's layout;
-// CW columns per lane, QN column quads stored per lane.
+// walker is a whole wave instruction however few lanes walk, and a tile's walk is
+// ~200 steps.
+//   * the only loop-carried position state is the two (negated) step counts; lane,
+//     column-in-lane and stored step of the current cell follow from them by one
+//     multiply-shift division, so a move is two conditional decrements;
+//   * the state machine runs on the packed kernel's op code (0 ZERO 1 MATCH 2 INSERT
+//     3 DELETE) and its inverted flags {ins_open<ins_extend, del_open<del_extend};
+//     the step limit (align.cpp:205) and the borders (:101-107) fold into the state,
+//     so the loop has one exit;
+//   * rescoring counts events (gap-extend columns, gap-open columns, equal-base MATCH
+//     columns, MATCH columns) and prices them once at the end.  With g(x) = "column x is a
+//     gap", a and b two columns adjacent in emission order: the right phase charges b when
+//     g(b), `extend` iff g(a); the left phase (columns arrive right to left) charges a when
+//     g(a), `extend` iff g(b).  Either way: g(a)&g(b) -> extend, else X -> open with
+//     X = g(a) in the left phase, g(b) in the right one;
+//   * pointer words come from the region cache (gact_device.hpp); inside a region the
+//     word of (lane, column, step) sits at c + 12*(k>>3) + off[lane == anchor ? 0 : 1].
+// rrow/qrow point at the LDS byte of DP row 1 / column 1; rstride is the ref stream's
+// byte stride.  (l0, c0, k0) = lane, column-in-lane and stored step of the start cell
+// (R, Q) in the pass's layout; CW columns per lane, QN column quads stored per lane.
 template <int CW, int FMT, int QN = CW / 4>
-__device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l, int c, int k,
+__device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
                                            int &query_steps, int &nst)
 {
-    int i = R, j = Q;
-    int is = 0, js = 0, n = 0, since = 0;
-    int state = GACT_STATE_Z;
-    uint32_t nib = 0;
-    TbRegion<CW> rg;
-    if (R >= 1 && Q >= 1 && early > 0) {
-        tb_refill_at<CW, QN>(ws, scratch, l, c, k, rg);
-        nib = tb_lookup_at<CW, FMT, QN>(scratch, l, c, k, rg);
-        state = nib & 3;
-    }
+    constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     const bool left = phase == 0;
-    int score = wk.score, pend = wk.pend_gap, openf = wk.open_flag, havel = wk.have_left, lfg = wk.left_first_gap;
+    const int p0 = l0 * CW + c0, kA = k0 - l0;
+    const int lim_i = imin(early, R), lim_j = imin(early, Q);
     const uint8_t *ra = rrow + (R - 1) * rstride;
     const uint8_t *qa = qrow + (Q - 1);
-    while (state != GACT_STATE_Z) {
-        // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209)
-        const int gap = state != GACT_STATE_M;
-        const int sub = (*ra == *qa) ? kp.match : kp.mismatch;
-        // left phase: the previously emitted column, if a gap, now learns its left neighbour;
-        // right phase: this column, if a gap, knows its left neighbour already
-        const int charge = left ? pend : gap;
-        const int nbr_gap = left ? gap : !openf;
-        score += charge ? (nbr_gap ? kp.ext : kp.open) : 0;
-        score += gap ? 0 : sub;
-        lfg = (left && !havel) ? gap : lfg;
-        havel = left ? 1 : havel;
-        pend = left ? gap : pend;
-        openf = left ? openf : !gap;
-        n++;
-        // ---- move (align.cpp:210-229)
-        const int isM = state == GACT_STATE_M, isI = state == GACT_STATE_I;
-        const int di = isM | isI, dj = isM | (state == GACT_STATE_D);
-        const int next = isM ? -1 : (isI ? ((nib & 8) ? GACT_STATE_M : GACT_STATE_I)
-                                         : ((nib & 4) ? GACT_STATE_M : GACT_STATE_D));
-        i -= di; j -= dj; is += di; js += dj;
-        ra -= di * rstride; qa -= dj;
-        c -= dj;
-        const int wrap = c < 0;
-        c += wrap ? CW : 0; l -= wrap; k -= di + wrap;
-        if (is >= early || js >= early || i < 1 || j < 1) break;       // align.cpp:205, borders :101-107
-        if (++since == kTbSpan) {
-            tb_refill_at<CW, QN>(ws, scratch, l, c, k, rg);
-            since = 0;
+    int nis = 0, njs = 0;                                       // minus the ref / query steps taken
+    int n_ext = 0, n_open = 0, n_eq = 0, n_m = 0;
+    uint32_t cur = 0, fl = 0;                                   // state (op-code numbering), flags of the current cell
+    TbRegion<CW> rg;
+    int off0 = 0, off1 = 0;
+
+    auto refill = [&](int l, int c, int k) {
+        tb_refill_at<CW, QN>(ws, scratch, l, c, k, rg);
+        off0 = -12 * rg.fbase[0] - 4 * rg.qbase0;
+        off1 = 24 - 12 * rg.fbase[1] - 4 * (QN - 3);
+    };
+    auto fetch = [&](int l, int c, int k, uint32_t &code, uint32_t &flags) {
+        const uint32_t w = scratch[c + 12 * (k >> 3) + (l == rg.l0 ? off0 : off1)];
+        if (FMT == 1) {
+            const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
+            code = v & 3u;
+            flags = (v >> 16) & 3u;
+        } else {
+            const uint32_t nib = w >> ((~(uint32_t)k & 7u) * 4u);
+            const uint32_t op = nib & 3u;                        // align.h:23 numbering Z0 D1 I2 M3
+            code = op ? 4u - op : 0u;
+            flags = (~nib >> 2) & 3u;
         }
-        nib = tb_lookup_at<CW, FMT, QN>(scratch, l, c, k, rg);
-        state = (next < 0) ? (int)(nib & 3) : next;
+    };
+
+    if (R >= 1 && Q >= 1 && early > 0) {
+        refill(l0, c0, k0);
+        fetch(l0, c0, k0, cur, fl);
     }
-    wk.score = score; wk.pend_gap = pend; wk.open_flag = openf; wk.have_left = havel; wk.left_first_gap = lfg;
-    ref_steps = is; query_steps = js; nst = n;
+    if (left && !wk.have_left && cur != 0) { wk.have_left = 1; wk.left_first_gap = cur != 1; }
+    int gprev = left ? wk.pend_gap : !wk.open_flag;
+    for (int it = 0; cur != 0; it++) {
+        // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209)
+        const int g = cur != 1;
+        const int eq = ra[nis * rstride] == qa[njs];
+        n_ext += gprev & g;
+        n_open += (gprev ^ g) & (left ? gprev : g);
+        n_m += !g;
+        n_eq += !g & eq;
+        gprev = g;
+        // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
+        nis -= cur != 3;
+        njs -= cur != 2;
+        const uint32_t forced = (fl & (4u - cur)) ? cur : 1u;
+        const int p = imax(p0 + njs, 0);
+        const int l = (int)(((uint32_t)p * kMagic) >> 16);
+        const int c = p - l * CW;
+        const int k = imax(kA + l + nis, 0);
+        if ((it & 7) == 7) refill(l, c, k);
+        uint32_t code;
+        fetch(l, c, k, code, fl);
+        const uint32_t nxt = cur == 1 ? code : forced;
+        cur = (-nis >= lim_i || -njs >= lim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
+    }
+    ref_steps = -nis; query_steps = -njs; nst = -nis - njs - n_m;
+    wk.score += n_ext * kp.ext + n_open * kp.open + n_eq * kp.match + (n_m - n_eq) * kp.mismatch;
+    wk.pend_gap = left ? gprev : wk.pend_gap;
+    wk.open_flag = left ? wk.open_flag : !gprev;
 }
 
 // after the traceback (gact.cpp:111-133 / :172-194); src = lane holding the walk's results

@@ -450,22 +450,10 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
     for (int n = 0; n < 12; n++) dst[n] = r[n];
 }
 
-// FMT 0: the int32 kernels' word, 8 rows x 4 bits {ins_open>=ins_extend, del_open>=del_extend, op}.
+// Pointer word formats (read by walk_chain, gact_chain.hpp):
+// FMT 0: the int32 kernels' word, 8 rows x 4 bits {ins_open>=ins_extend, del_open>=del_extend, op}, first row on top.
 // FMT 1: the packed kernel's word, low half 8 rows x 2 bits op code (0 ZERO 1 MATCH 2 INSERT 3 DELETE),
-//        high half 8 rows x 2 bits {ins_open<ins_extend, del_open<del_extend}.  Both return the FMT 0 nibble.
-template <int CW, int FMT, int QN = CW / 4>
-__device__ __forceinline__ uint32_t tb_lookup_at(const uint32_t *scratch, int l, int c, int k, const TbRegion<CW> &rg)
-{
-    const int sl = rg.l0 - l;                                   // 0 or 1
-    const int lev = (k >> 3) - (sl ? rg.fbase[1] : rg.fbase[0]);
-    const int qq = (c >> 2) - (sl ? QN - 3 : rg.qbase0);
-    const uint32_t w = scratch[(((sl * 2 + lev) * 3 + qq) << 2) + (c & 3)];
-    if (FMT == 0) return (w >> (28 - 4 * (k & 7))) & 15u;
-    const int sh = 14 - 2 * (k & 7);
-    const uint32_t code = (w >> sh) & 3u, nfl = ~(w >> (sh + 16)) & 3u;
-    const uint32_t state = code ? 4u - code : 0u;              // -> align.h:23 numbering Z0 D1 I2 M3
-    return state | (nfl << 2);                                 // bit3 ins flag, bit2 del flag
-}
+//        high half 8 rows x 2 bits {ins_open<ins_extend, del_open<del_extend}.
 
 // ---------------------------------------------------------------------------
 // Loads one group's tile into LDS + registers.  DP index d (0-based) of a

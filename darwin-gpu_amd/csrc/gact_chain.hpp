@@ -205,8 +205,11 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         off0 = -12 * rg.fbase[0] - 4 * rg.qbase0;
         off1 = 24 - 12 * rg.fbase[1] - 4 * (QN - 3);
     };
+    // 32-bit LDS addressing (through the generic pointer the index arithmetic is done in 64 bits)
+    typedef __attribute__((address_space(3))) const uint32_t LdsWord;
+    LdsWord *cache = (LdsWord *)scratch;
     auto fetch = [&](int l, int c, int k, uint32_t &code, uint32_t &flags) {
-        const uint32_t w = scratch[c + 12 * (k >> 3) + (l == rg.l0 ? off0 : off1)];
+        const uint32_t w = cache[c + (int)__umul24((uint32_t)k >> 3, 12u) + (l == rg.l0 ? off0 : off1)];
         if (FMT == 1) {
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
@@ -239,8 +242,8 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         njs -= cur != 2;
         const uint32_t forced = (fl & (4u - cur)) ? cur : 1u;
         const int p = imax(p0 + njs, 0);
-        const int l = (int)(((uint32_t)p * kMagic) >> 16);
-        const int c = p - l * CW;
+        const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
+        const int c = p + __mul24(l, -CW);
         const int k = imax(kA + l + nis, 0);
         if ((it & 7) == 7) refill(l, c, k);
         uint32_t code;

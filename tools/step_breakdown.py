@@ -17,11 +17,17 @@ offs[1:] = np.cumsum([len(r) for r in reads])
 cat = np.concatenate(reads)
 rcat = np.concatenate([synth.revcomp(r) for r in reads])
 eng = engine.Engine(n_slots=1)
-eng.upload(engine.SET_REF, cat, offs)
-eng.upload(engine.SET_QUERY, cat, offs)
-eng.upload(engine.SET_QUERY_RC, rcat, offs)
 nf, nr = len(blk.cf), len(blk.cr)
-eng.candidates_upload(np.concatenate([blk.cf, blk.cr]), slot=0)
+for rep in range(2):
+    t0 = time.perf_counter()
+    eng.upload(engine.SET_REF, cat, offs)
+    eng.upload(engine.SET_QUERY, cat, offs)
+    eng.upload(engine.SET_QUERY_RC, rcat, offs)
+    t1 = time.perf_counter()
+    eng.candidates_upload(np.concatenate([blk.cf, blk.cr]), slot=0)
+    t2 = time.perf_counter()
+    print("upload: 3 read sets (%.1f MB, incl. 2-bit packing on the device) %.2f ms, %d candidates %.2f ms"
+          % (3 * len(cat) / 1e6, (t1 - t0) * 1e3, nf + nr, (t2 - t1) * 1e3))
 for it in range(5):
     eng.sync(0)
     t0 = time.perf_counter()

@@ -191,17 +191,9 @@ int check_slot(gact_hip_engine *e, int slot)
     return 0;
 }
 
-// upload + pack one set on `stream`
-int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, const int64_t *offsets,
-               int32_t n_seqs)
+// device buffers of a set for `total` bases in n_seqs sequences
+int reserve_set(SeqSet &s, int64_t total, int32_t n_seqs)
 {
-    if (n_seqs < 0 || (n_seqs > 0 && (!offsets || !concat && offsets[n_seqs] > 0)))
-        return fail(GACT_HIP_EINVAL, "upload: bad arguments");
-    const int64_t total = n_seqs ? offsets[n_seqs] : 0;
-    if (n_seqs && offsets[0] != 0) return fail(GACT_HIP_EINVAL, "upload: offsets[0] must be 0");
-    for (int32_t k = 0; k < n_seqs; k++)
-        if (offsets[k + 1] < offsets[k]) return fail(GACT_HIP_EINVAL, "upload: offsets not monotone");
-
     const size_t need_bases = (size_t)total + 64;
     if (need_bases > s.cap_bases) {
         if (s.d_raw) (void)hipFree(s.d_raw);
@@ -218,6 +210,22 @@ int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, c
         HIP_TRY(hipMalloc((void **)&s.d_offsets, need_seqs * sizeof(int64_t)));
         s.cap_seqs = need_seqs;
     }
+    return 0;
+}
+
+// upload + pack one set on `stream`
+int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, const int64_t *offsets,
+               int32_t n_seqs)
+{
+    if (n_seqs < 0 || (n_seqs > 0 && (!offsets || !concat && offsets[n_seqs] > 0)))
+        return fail(GACT_HIP_EINVAL, "upload: bad arguments");
+    const int64_t total = n_seqs ? offsets[n_seqs] : 0;
+    if (n_seqs && offsets[0] != 0) return fail(GACT_HIP_EINVAL, "upload: offsets[0] must be 0");
+    for (int32_t k = 0; k < n_seqs; k++)
+        if (offsets[k + 1] < offsets[k]) return fail(GACT_HIP_EINVAL, "upload: offsets not monotone");
+
+    int rc_alloc = reserve_set(s, total, n_seqs);
+    if (rc_alloc) return rc_alloc;
     s.h_offsets.assign(offsets, offsets + n_seqs + 1);
     if (n_seqs == 0) s.h_offsets.assign(1, 0);
     s.n = n_seqs; s.total = total;
@@ -518,6 +526,41 @@ int gact_hip_upload_seqs(gact_hip_engine *e, int which, const uint8_t *concat, c
     int rc = set_device(e);
     if (rc) return rc;
     return upload_set(e, e->sets[which], e->slots[0], concat, offsets, n_seqs);
+}
+
+int gact_hip_derive_revcomp(gact_hip_engine *e)
+{
+    if (!e) return fail(GACT_HIP_EINVAL, "engine is NULL");
+    std::lock_guard<std::mutex> lk(e->upload_mu);
+    int rc = set_device(e);
+    if (rc) return rc;
+    const SeqSet &qf = e->sets[GACT_SET_QUERY];
+    SeqSet &qr = e->sets[GACT_SET_QUERY_RC];
+    if (qf.n == 0 || !qf.d_raw) return fail(GACT_HIP_EINVAL, "derive_revcomp: GACT_SET_QUERY has not been uploaded");
+    Slot &sl = e->slots[0];
+    if ((rc = reserve_set(qr, qf.total, qf.n))) return rc;
+    qr.h_offsets = qf.h_offsets; qr.n = qf.n; qr.total = qf.total; qr.max_len = qf.max_len;
+    HIP_TRY(hipMemcpyAsync(qr.d_offsets, qf.d_offsets, qf.h_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToDevice,
+                           sl.stream));
+    HIP_TRY(hipMemsetAsync(sl.d_flags, 0, sizeof(int), sl.stream));
+    const int threads = 256;
+    const int blocks = (int)std::min<int64_t>((qf.total + threads - 1) / threads, 1 << 16);
+    hipLaunchKernelGGL(gact::revcomp_kernel, dim3(std::max(blocks, 1)), dim3(threads), 0, sl.stream, qf.d_raw,
+                       qf.d_offsets, qf.n, qf.total, qr.d_raw, sl.d_flags);
+    const int64_t n_words = (qf.total + 15) / 16 + 2;
+    const int pblocks = (int)std::min<int64_t>((n_words + threads - 1) / threads, 4096);
+    hipLaunchKernelGGL(gact::pack_kernel, dim3(std::max(pblocks, 1)), dim3(threads), 0, sl.stream, qr.d_raw, qf.total,
+                       qr.d_packed, n_words, sl.d_flags);
+    HIP_TRY(hipGetLastError());
+    int flags = 0;
+    HIP_TRY(hipMemcpyAsync(&flags, sl.d_flags, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    if (flags & 2) {
+        qr.n = 0; qr.total = 0;
+        return fail(GACT_HIP_EINVAL, "derive_revcomp: Bad Nt char in GACT_SET_QUERY (darwin.cpp:139-141)");
+    }
+    qr.has_other = (flags & 1) != 0;
+    return 0;
 }
 
 int gact_hip_align_tiles(gact_hip_engine *e, int slot, int32_t n, const gact_tile *tiles,

@@ -275,6 +275,34 @@ __global__ void pack_kernel(const uint8_t *__restrict__ raw, int64_t n_bases,
 
 
 // ---------------------------------------------------------------------------
+// reverse complement of a whole read set (darwin.cpp:110-147): out[off[r] + len-1-i] = comp(in[off[r] + i]);
+// flags[0] |= 2 when a byte is none of acgtnACGTN
+__global__ void revcomp_kernel(const uint8_t *__restrict__ raw, const int64_t *__restrict__ offsets, int n_seqs,
+                               int64_t n_bases, uint8_t *__restrict__ out, int *__restrict__ flags)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_bases; p += stride) {
+        int lo = 0, hi = n_seqs - 1;                     // last sequence with offsets[r] <= p
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (offsets[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        uint8_t c;
+        switch (raw[p]) {
+            case 'a': c = 't'; break; case 'A': c = 'T'; break;
+            case 'c': c = 'g'; break; case 'C': c = 'G'; break;
+            case 'g': c = 'c'; break; case 'G': c = 'C'; break;
+            case 't': c = 'a'; break; case 'T': c = 'A'; break;
+            case 'n': c = 'n'; break; case 'N': c = 'N'; break;
+            default: c = 'N'; bad = true;
+        }
+        out[offsets[lo] + (offsets[lo + 1] - 1 - p)] = c;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 2);
+}
+
+// ---------------------------------------------------------------------------
 // Integer-VALU issue-rate probe: 16 independent v_add_u32 / v_max_i32 chains
 // per lane, nothing else.  Gives the measured int32 lane-op/s ceiling the
 // roofline fraction in bench.py is priced against.

@@ -152,7 +152,8 @@ def load():
     L.gact_hip_dsoft_build.argtypes = [vp, C.POINTER(DsoftParams), C.POINTER(DsoftInfo)]
     L.gact_hip_dsoft_query.argtypes = [vp, C.c_int, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     L.gact_hip_candidates_download.argtypes = [vp, C.c_int, i32, vp]
-    for name in ("dsoft_build", "dsoft_query", "candidates_download", "create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
+    L.gact_hip_derive_revcomp.argtypes = [vp]
+    for name in ("derive_revcomp", "dsoft_build", "dsoft_query", "candidates_download", "create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
                  "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range", "candidates_run_mixed",
                  "candidates_fetch", "sync", "last_kernel_ms", "last_run_stats", "format_overlap"):
         getattr(L, "gact_hip_" + name).restype = C.c_int
@@ -166,7 +167,7 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_candidates_run_range", "gact_hip_candidates_run_mixed", "gact_hip_candidates_fetch", "gact_hip_sync",
            "gact_hip_last_kernel_ms", "gact_hip_last_run_stats", "gact_hip_device_overlaps", "gact_hip_stream",
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
-           "gact_hip_candidates_download")
+           "gact_hip_candidates_download", "gact_hip_derive_revcomp")
 
 
 class Engine:
@@ -209,6 +210,10 @@ class Engine:
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         self._check(self.L.gact_hip_upload_seqs(self.h, which, concat.ctypes.data, offsets.ctypes.data,
                                                 len(offsets) - 1))
+
+    def derive_revcomp(self):
+        """SET_QUERY_RC := reverse complement of SET_QUERY, on the device (darwin.cpp:110-147)"""
+        self._check(self.L.gact_hip_derive_revcomp(self.h))
 
     def upload_seqs(self, which, seqs):
         seqs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else

@@ -287,7 +287,8 @@ int main(int argc, char *argv[])
 
     parse_fasta(ref_path, reference_descrips, reference_seqs, reference_lengths);
     parse_fasta(reads_path, reads_descrips, reads_seqs, reads_lengths);
-    for (const std::string &r : reads_seqs) rev_reads_seqs.push_back(rev_comp(r));
+    if (!device_dsoft)
+        for (const std::string &r : reads_seqs) rev_reads_seqs.push_back(rev_comp(r));
     std::cout << "Number of reads: " << reads_seqs.size() << std::endl;
 
     if (device_dsoft) {
@@ -297,7 +298,7 @@ int main(int argc, char *argv[])
         gact_hip_engine *e = (gact_hip_engine *)s[0].engine;
         upload_set(e, GACT_SET_REF, reference_seqs);
         upload_set(e, GACT_SET_QUERY, reads_seqs);
-        upload_set(e, GACT_SET_QUERY_RC, rev_reads_seqs);
+        if (gact_hip_derive_revcomp(e) != 0) { std::cerr << gact_hip_last_error() << std::endl; return 1; }   // darwin.cpp:110-147
         gact_dsoft_params gp = {dp.seed_size, (int32_t)dp.bin_size, (int32_t)dp.window_size, dp.threshold, dp.num_seeds,
                                 (int32_t)dp.seed_occurence_multiple, dp.max_candidates};
         gact_dsoft_info info;

@@ -97,6 +97,14 @@ int gact_hip_get_device_info(gact_hip_engine *e, gact_hip_device_info *info);
 int gact_hip_upload_seqs(gact_hip_engine *e, int which_set,
                          const uint8_t *concat, const int64_t *offsets, int32_t n_seqs);
 
+/*
+ * GACT_SET_QUERY_RC := reverse complement of every sequence of GACT_SET_QUERY, made on the device
+ * (stands where darwin.cpp:110-147 builds rev_reads_seqs on the host; saves the third upload).
+ * Complement as darwin.cpp:122-142: a<->t, c<->g in either case, n and N stay; any other byte is an
+ * error (the reference prints "Bad Nt char" and exits).
+ */
+int gact_hip_derive_revcomp(gact_hip_engine *e);
+
 /* ---- per-tile batch: what Align_Batch_GPU does (cuda_host.cu:23-190) ---- */
 
 /*

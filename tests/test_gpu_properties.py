@@ -92,3 +92,34 @@ def test_kernel_families_agree_at_size(setup, monkeypatch):
         assert e2.last_run_stats()["layout"] != "packed16-split"
         assert got.tobytes() == base.tobytes()
         e2.close()
+
+
+def test_revcomp_on_device_equals_uploaded_set(oracle):
+    """gact_hip_derive_revcomp (darwin.cpp:110-147 on the device): extending the reverse-complement candidates
+    against the derived set gives the records of the uploaded host-made set, with N and lower case in the reads;
+    a byte outside acgtnACGTN is refused like the reference's 'Bad Nt char'"""
+    from gact_amd import engine, synth
+    rs = synth.simulate_reads(20000, n_reads=16, seed=91, mean_len=4000, sd_len=1500, min_len=50, max_len=9000,
+                              n_frac=0.003)
+    reads = [np.array(r) for r in rs.reads]
+    reads[2][10:40] = np.frombuffer(bytes(reads[2][10:40]).lower(), dtype=np.uint8)
+    _, cr = synth.synth_candidates(rs, seed=92, min_overlap=300)
+    assert len(cr) > 20
+    recs = []
+    for derive in (False, True):
+        eng = engine.Engine()
+        eng.upload_seqs(engine.SET_REF, reads)
+        eng.upload_seqs(engine.SET_QUERY, reads)
+        if derive:
+            eng.derive_revcomp()
+        else:
+            eng.upload_seqs(engine.SET_QUERY_RC, [synth.revcomp(r) for r in reads])
+        recs.append(eng.extend(cr, complement=True))
+        eng.close()
+    for name in recs[0].dtype.names:
+        assert np.array_equal(recs[0][name], recs[1][name]), name
+    eng = engine.Engine()
+    eng.upload_seqs(engine.SET_QUERY, [np.frombuffer(b"ACGTXACGT", dtype=np.uint8)])
+    with pytest.raises(engine.GactHipError):
+        eng.derive_revcomp()
+    eng.close()

@@ -181,6 +181,7 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
     }
     uint32_t Mo_last = kc.open, D_last = kc.ninf, Hm_last = kc.match;
     uint32_t Hm_left_prev = kc.match;
+    uint32_t Ml0 = kc.open, Dl0 = kc.ninf, Hl = kc.match;       // what lane gl-1 shows
 
     // arg-max state (AMAX only; RQ[h] = {R, Q} of tile h, no start delay: first tiles store from step 1)
     uint32_t bk[AMAX ? C : 1];
@@ -210,9 +211,10 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
             key_c = ka | (kb << 16);
         }
 
-        const uint32_t Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)kc.open);
-        const uint32_t Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)kc.ninf);
-        const uint32_t Hl = (uint32_t)dpp_row_shr1((int)Hm_last, (int)kc.match);
+        // lane 0 of each destination keeps what it held: the j = 0 border it was initialised with
+        Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)Ml0);
+        Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)Dl0);
+        Hl = (uint32_t)dpp_row_shr1((int)Hm_last, (int)Hl);
         uint32_t Hd = Hm_left_prev;
         Hm_left_prev = Hl;
 

@@ -46,7 +46,7 @@ template <int C1, int C2> struct GeometrySplit {
 __device__ __forceinline__ int dpp_row_ror1(int v)
 {
     // lane n of each 16-lane row reads lane n-1, lane 0 reads lane 15
-    return __builtin_amdgcn_update_dpp(0, v, 0x121, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, 0x121, 0xF, 0xF, false);      // every lane is written: no `old` operand
 }
 
 template <int C2> __device__ __forceinline__ int split_last_step(int R, int Q)
@@ -87,7 +87,7 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
     uint32_t Mo1 = kc.open, D1 = kc.ninf, H1 = kc.match;
     uint32_t Mo2 = kc.open, D2 = kc.ninf, H2 = kc.match;
     uint32_t Hdiag1 = kc.match, Hdiag2 = kc.match;
-    const bool last_lane = gl == kGroup - 1;
+    uint32_t Ml1 = kc.open, Dl1 = kc.ninf, Hl1 = kc.match;      // what lane gl-1 shows; lane 0 keeps the border
 
     auto unpack = [](uint32_t w) { return (w & 0xffu) | ((w & 0xff00u) << 8); };
     uint32_t rb1 = unpack(ref16[1]), rb2 = unpack(ref16[1 - LAG]);
@@ -96,14 +96,17 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
         constexpr bool PTR = decltype(ptr_tag)::value;
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
 
-        // region 1: lane 0 sits on the j = 0 border (or on left pads, which behave like it)
-        const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)Mo1, (int)kc.open);
-        const uint32_t Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)kc.ninf);
-        const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)kc.match);
-        // region 2: lane 0 continues lane 15's region 1 (computed one step ago = same row)
-        const uint32_t Ml2 = (uint32_t)dpp_row_ror1((int)(last_lane ? Mo1 : Mo2));
-        const uint32_t Dl2 = (uint32_t)dpp_row_ror1((int)(last_lane ? D1 : D2));
-        const uint32_t Hl2 = (uint32_t)dpp_row_ror1((int)(last_lane ? H1 : H2));
+        // region 1: lane 0 sits on the j = 0 border (or on left pads, which behave like it).  The border value is
+        // whatever lane 0 of the destination held before: the previous step's result, i.e. the border again --
+        // no register has to be re-loaded with it
+        Ml1 = (uint32_t)dpp_row_shr1((int)Mo1, (int)Ml1);
+        Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
+        Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Hl1);
+        // region 2: lane 0 continues lane 15's region 1 (computed one step ago = same row): rotate region 1's
+        // values into place, then shift region 2's over every lane but lane 0
+        const uint32_t Ml2 = (uint32_t)dpp_row_shr1((int)Mo2, dpp_row_ror1((int)Mo1));
+        const uint32_t Dl2 = (uint32_t)dpp_row_shr1((int)D2, dpp_row_ror1((int)D1));
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)H1));
         uint32_t Hd = Hdiag1;
         Hdiag1 = Hl1;
 

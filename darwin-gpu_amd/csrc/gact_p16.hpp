@@ -197,7 +197,7 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         rows[0] = RQ[0][0]; rows[1] = RQ[1][0];
     }
 
-    auto unpack = [](uint32_t w) { return (w & 0xffu) | ((w & 0xff00u) << 8); };
+    auto unpack = [](uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); };      // {byte 1, byte 0} -> two half-words
     uint32_t rbp = unpack(ref16[1]);
 
     auto step = [&](const int t, auto ptr_tag) {

@@ -89,7 +89,7 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
     uint32_t Hdiag1 = kc.match, Hdiag2 = kc.match;
     uint32_t Ml1 = kc.open, Dl1 = kc.ninf, Hl1 = kc.match;      // what lane gl-1 shows; lane 0 keeps the border
 
-    auto unpack = [](uint32_t w) { return (w & 0xffu) | ((w & 0xff00u) << 8); };
+    auto unpack = [](uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); };      // {byte 1, byte 0} -> two half-words
     uint32_t rb1 = unpack(ref16[1]), rb2 = unpack(ref16[1 - LAG]);
 
     auto step = [&](const int t, auto ptr_tag) {

@@ -301,9 +301,11 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     const int64_t longest = std::min(rs.max_len, std::max(need_f ? qf.max_len : 0, need_r ? qr.max_len : 0));
     kp.prio_bases[0] = e->chain_prio ? (int32_t)std::min<int64_t>(longest / 3, 0x7fffffff) : 0x7fffffff;
     kp.prio_bases[1] = e->chain_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : 0x7fffffff;
+    // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
     if (e->seed16) {
         const int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
-        hipLaunchKernelGGL((gact::seed_p16_kernel<C>), dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
+        auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
+        hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
                            kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
                            same_file, sl.overlaps.p, queues(sl), sl.d_ws);
     } else {
@@ -315,14 +317,12 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     sl.two_phase = e->p16;
     if (e->p16) {
         HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
-        if (e->split)
-            hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayout<7, 13>>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
-                               sl.stream, kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
-                               same_file, sl.overlaps.p, queues(sl), sl.d_ws);
-        else
-            hipLaunchKernelGGL((gact::extend_p16_kernel<gact::UniformLayout<C>>), dim3(main_blocks), dim3(gact::kBlockThreads), 0,
-                               sl.stream, kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs),
-                               same_file, sl.overlaps.p, queues(sl), sl.d_ws);
+        auto km = e->split ? (raw ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
+                                  : gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>)
+                           : (raw ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
+                                  : gact::extend_p16_kernel<gact::UniformLayout<C>, false>);
+        hipLaunchKernelGGL(km, dim3(main_blocks), dim3(gact::kBlockThreads), 0, sl.stream, kp, e->kc, rs.dev(raw),
+                           qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file, sl.overlaps.p, queues(sl), sl.d_ws);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -333,19 +333,26 @@ template <int C> int occupancy_blocks(int *out)
     int a = 0, b = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
-    int c = a;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::extend_p16_kernel<gact::UniformLayout<C>>, gact::kBlockThreads, 0));
-    int d = c;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, gact::extend_p16_kernel<gact::SplitLayout<7, 13>>, gact::kBlockThreads, 0));
-    *out = std::max(1, std::min(std::min(a, b), std::min(c, d)));
+    int m = std::min(a, b);
+    for (int v = 0; v < 4; v++) {
+        int c = m;
+        auto k = v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
+               : v == 1 ? gact::extend_p16_kernel<gact::UniformLayout<C>, false>
+               : v == 2 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
+                        : gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k, gact::kBlockThreads, 0));
+        m = std::min(m, c);
+    }
+    *out = std::max(1, m);
     return 0;
 }
 
 template <int C> int seed_occupancy_blocks(int *out)
 {
-    int a = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::seed_p16_kernel<C>, gact::kBlockThreads, 0));
-    *out = std::max(1, a);
+    int a = 0, b = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::seed_p16_kernel<C, true>, gact::kBlockThreads, 0));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::seed_p16_kernel<C, false>, gact::kBlockThreads, 0));
+    *out = std::max(1, std::min(a, b));
     return 0;
 }
 
@@ -450,6 +457,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);
     e->kc.open = gact::pk2(p->gap_open); e->kc.ext = gact::pk2(p->gap_extend);
     e->kc.ninf = gact::pk2(gact::kNegInf16); e->kc.one = gact::pk2(1);
+    e->kc.mism = gact::pk2(p->mismatch); e->kc.dsub = (uint32_t)(p->match - p->mismatch) << 24;
 
     rc = (e->C == 20) ? occupancy_blocks<20>(&e->blocks_per_cu) : occupancy_blocks<32>(&e->blocks_per_cu);
     if (rc) { delete e; return rc; }

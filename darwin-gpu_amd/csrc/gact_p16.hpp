@@ -37,6 +37,8 @@ constexpr int kSlots = 2;                  // tiles per 16-lane group (low / hig
 // scoring constants replicated into both half-words
 struct P16Consts {
     uint32_t match, nd /* mismatch - match */, open, ext, ninf, one;
+    uint32_t mism;      // mismatch in both half-words
+    uint32_t dsub;      // (match - mismatch) << 24 (LUT form of the substitution score)
 };
 
 __host__ __device__ inline uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -46,7 +48,7 @@ __host__ __device__ inline uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) 
 __host__ inline bool p16_scoring_ok(int tile, int match, int mismatch, int open, int ext)
 {
     return match >= 0 && (long long)match * (tile + 2) <= 12000 && mismatch >= -4000 && open >= -4000 &&
-           ext >= -4000 && open - ext > kNegInf16 + 64;
+           ext >= -4000 && open - ext > kNegInf16 + 64 && match - mismatch <= 127;
 }
 
 #define GACT_PK2(name, op)                                                                        \
@@ -158,7 +160,14 @@ template <int C> struct GeometryP16 {
 // current 8-step block (a later row wins a tie; rows outside 1..R are keyed negative); at every flush the
 // slots of a lane are folded in column order (a later column wins a tie, columns past Q masked) into one
 // 32-bit (H, step, column) record per tile, and the 16 lanes are merged at the end.
-template <int C, bool AMAX = false>
+//
+// Substitution score, two forms.  RAW (sets holding bytes other than ACGT, compared as raw bytes like
+// align.cpp:134): x = q ^ r, neq = min(x, 1), Mx = (H + match) + neq * (mismatch - match): 3 ops per cell pair.
+// Otherwise (2-bit sets): every step builds one look-up word per tile, byte k = (k == r) ? match - mismatch : 0
+// (one right shift of (match - mismatch) << 24 by the row's stream byte, 24 - 8 r; a pad row's byte is 31 and
+// shifts everything out), and a slot's v_perm_b32 -- its selector bytes are the two query codes, fixed per
+// tile -- picks both tiles' values at once; Mx = (H + mismatch) + that: 2 ops per cell pair.
+template <int C, bool AMAX = false, bool RAW = true>
 __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                                             const uint16_t *__restrict__ ref16,
                                             const uint32_t (&qb)[C],
@@ -166,7 +175,8 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                                             uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
                                             const int (*RQ)[2] = nullptr, P16Best *pb = nullptr)
 {
-    uint32_t Hm[C], Mo[C], Iup[C];          // H+match, M+open, I of the previous row (both tiles)
+    const uint32_t hbias = RAW ? kc.match : kc.mism;
+    uint32_t Hm[C], Mo[C], Iup[C];          // H+bias, M+open, I of the previous row (both tiles)
     // Pointer bits, packed for both tiles (tile A low half-word, tile B high), 8 rows per half-word:
     //   accO  2 bits/row  op code  0 ZERO, 1 MATCH, 2 INSERT, 3 DELETE   = nz * (1 + na * (1 + nb))
     //   accF  2 bits/row  {ins_open < ins_extend, del_open < del_extend}  (the complements of align.cpp:170-171)
@@ -174,14 +184,14 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
     uint32_t accO[C], accF[C];
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        Hm[c] = kc.match;                   // H[0][j] = 0
+        Hm[c] = hbias;                      // H[0][j] = 0
         Mo[c] = kc.open;                    // M[0][j] + gap_open
         Iup[c] = kc.ninf;                   // I[0][j] = -INF
         accO[c] = 0; accF[c] = 0;
     }
-    uint32_t Mo_last = kc.open, D_last = kc.ninf, Hm_last = kc.match;
-    uint32_t Hm_left_prev = kc.match;
-    uint32_t Ml0 = kc.open, Dl0 = kc.ninf, Hl = kc.match;       // what lane gl-1 shows
+    uint32_t Mo_last = kc.open, D_last = kc.ninf, Hm_last = hbias;
+    uint32_t Hm_left_prev = hbias;
+    uint32_t Ml0 = kc.open, Dl0 = kc.ninf, Hl = hbias;          // what lane gl-1 shows
 
     // arg-max state (AMAX only; RQ[h] = {R, Q} of tile h, no start delay: first tiles store from step 1)
     uint32_t bk[AMAX ? C : 1];
@@ -197,8 +207,16 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         rows[0] = RQ[0][0]; rows[1] = RQ[1][0];
     }
 
-    auto unpack = [](uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); };      // {byte 1, byte 0} -> two half-words
-    uint32_t rbp = unpack(ref16[1]);
+    // RAW: the two ref bases as half-words.  LUT: entry bytes are 24 - 8 * code (31 for a pad row), so the
+    // shift leaves match - mismatch in byte `code`, or nothing
+    auto unpack = [](uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); };
+    auto lut = [&](uint32_t amount) { return kc.dsub >> (amount & 31u); };
+    uint32_t rbp = 0, lutA = 0, lutB = 0;
+    auto set_row = [&](uint32_t w) {
+        if (RAW) rbp = unpack(w);
+        else { lutA = lut(w & 0xffu); lutB = lut(w >> 8); }
+    };
+    set_row(ref16[1]);
 
     auto step = [&](const int t, auto ptr_tag) {
         constexpr bool PTR = decltype(ptr_tag)::value;
@@ -221,9 +239,10 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         uint32_t M[C];
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            // sub = (q==r) ? match : mismatch, as match + (q!=r)*(mismatch-match)   (align.cpp:134)
-            const uint32_t neq = pk_min1(qb[c] ^ rbp);
-            const uint32_t Mx = pk_mad_s(neq, kc.nd, Hd);          // (H[i-1][j-1] + match) + neq*nd
+            // sub = (q==r) ? match : mismatch   (align.cpp:134)
+            uint32_t Mx;
+            if (RAW) Mx = pk_mad_s(pk_min1(qb[c] ^ rbp), kc.nd, Hd);                 // (H[i-1][j-1] + match) + neq*nd
+            else Mx = pk_add(Hd, __builtin_amdgcn_perm(lutB, lutA, qb[c]));         // (H[i-1][j-1] + mismatch) + eq*d
             Hd = Hm[c];
             M[c] = pk_max0(Mx);                                     // :145-147
             const uint32_t Ie = pk_add_s(Iup[c], kc.ext);           // ins_extend :150
@@ -247,14 +266,14 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                 accO[c] = pk_shl_add4(accO[c], pk_mad_vvv(nz, o, nz));
             }
             if (AMAX) bk[c] = pk_max(bk[c], pk_mad8(H, key_c));
-            Hm[c] = pk_add_s(H, kc.match);
+            Hm[c] = pk_add_s(H, hbias);
             Ml = Mo[c];
             Dl = D;
         }
         Mo_last = Ml;
         D_last = Dl;
         Hm_last = Hm[C - 1];
-        rbp = unpack(w_next);
+        set_row(w_next);
     };
 
     // tile A's word = {accF.lo, accO.lo}, tile B's = {accF.hi, accO.hi}: flags in the high half-word
@@ -343,8 +362,11 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
 }
 
 // ---------------------------------------------------------------------------
-// Loads the two tiles of a group: packed query codes into qb, ref stream and
-// query bytes into LDS.  The ref stream must have been filled with pad bytes.
+// Loads the two tiles of a group: ref stream and query bytes into LDS, per-slot query operand into qb.
+// RAW: bytes as they are (raw set bytes or 2-bit codes), pads 0xFF / 0xFE, qb = the two query bytes as half-words.
+// Otherwise (2-bit sets, LUT form of dp_pass_p16): LDS bytes are 24 - 8 * code, a pad row is 31, a pad column
+// 0xFE; qb = v_perm selector {code of tile A, zero, 4 + code of tile B, zero}, a pad column selects the constant 0.
+constexpr uint32_t kLutPadRow = 31, kPermZero = 0x0c;
 struct PairTile {
     int R[kSlots], Q[kSlots], shift[kSlots];
     bool reverse[kSlots];
@@ -352,8 +374,8 @@ struct PairTile {
     int comp[kSlots];
 };
 
-template <int C>
-__device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc, bool raw,
+template <int C, bool RAW>
+__device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc,
                                           const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8,
                                           uint32_t (&qb)[C])
 {
@@ -361,25 +383,21 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
     // pad the whole stream: rows in front of row 1 (skew + start delay) and behind row R
     GACT_STAMP(l_a);
     uint32_t *ref32 = reinterpret_cast<uint32_t *>(ref8);
-    for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = 0xffffffffu;
+    for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = RAW ? 0xffffffffu : kLutPadRow * 0x01010101u;
     wave_sync();
     GACT_STAMP(l_b);
     // all loads first (addresses clamped into the slice, never predicated, so they are all in
     // flight together), pads substituted afterwards
     uint32_t rv[kSlots][C], qv[kSlots][C];
-    auto issue = [&](auto raw_tag) {
-        constexpr bool RAW = decltype(raw_tag)::value;
 #pragma unroll
-        for (int h = 0; h < kSlots; h++) {
-            const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
+    for (int h = 0; h < kSlots; h++) {
+        const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
 #pragma unroll
-            for (int c = 0; c < C; c++) {
-                rv[h][c] = fetch_base<RAW>(rs, slice_pos(pt.rp0[h], pt.R[h], pt.reverse[h], gl * C + c));
-                qv[h][c] = fetch_base<RAW>(qs, slice_pos(pt.qp0[h], pt.Q[h], pt.reverse[h], gl * C + c));
-            }
+        for (int c = 0; c < C; c++) {
+            rv[h][c] = fetch_base<RAW>(rs, slice_pos(pt.rp0[h], pt.R[h], pt.reverse[h], gl * C + c));
+            qv[h][c] = fetch_base<RAW>(qs, slice_pos(pt.qp0[h], pt.Q[h], pt.reverse[h], gl * C + c));
         }
-    };
-    if (raw) issue(std::true_type{}); else issue(std::false_type{});
+    }
 #ifdef GACT_STAMPS
     { uint32_t x = 0;
 #pragma unroll
@@ -390,7 +408,7 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 #endif
     GACT_STAMP(l_c);
 #pragma unroll
-    for (int c = 0; c < C; c++) qb[c] = 0;
+    for (int c = 0; c < C; c++) qb[c] = RAW ? 0u : kPermZero * 0x01010101u;
 #pragma unroll
     for (int h = 0; h < kSlots; h++) {
         const int R = pt.R[h], Q = pt.Q[h];
@@ -398,10 +416,16 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int d = gl * C + c;
-            const uint32_t qcode = (d < Q) ? qv[h][c] : kQueryPad;
-            if (d < R) rrow[d * 2] = (uint8_t)rv[h][c];
-            q8[h * G::kTileMax + d] = (uint8_t)qcode;
-            qb[c] |= qcode << (16 * h);
+            if (RAW) {
+                const uint32_t qcode = (d < Q) ? qv[h][c] : kQueryPad;
+                if (d < R) rrow[d * 2] = (uint8_t)rv[h][c];
+                q8[h * G::kTileMax + d] = (uint8_t)qcode;
+                qb[c] |= qcode << (16 * h);
+            } else {
+                if (d < R) rrow[d * 2] = (uint8_t)(24u - rv[h][c] * 8u);
+                q8[h * G::kTileMax + d] = (uint8_t)((d < Q) ? 24u - qv[h][c] * 8u : kQueryPad);
+                if (d < Q) qb[c] = (qb[c] & ~(0xffu << (16 * h))) | ((qv[h][c] + 4u * h) << (16 * h));
+            }
         }
     }
 #ifdef GACT_STAMPS
@@ -424,12 +448,14 @@ template <int C> struct UniformLayout {
     static constexpr int kRow0 = kGroup;                          // ref stream entry of (delay 0, row 1)
     __device__ static int last_step(int R, int Q) { return gact::last_step<C>(R, Q); }
     __device__ static int first_pointer_step(int R, int Q, int early) { return gact::first_pointer_step<C>(R, Q, early, false); }
-    __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr, bool raw,
+    template <bool RAW>
+    __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr,
                                 const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C])
-    { load_pair<C>(rs, qf, qr, raw, pt, gl, ref8, q8, qb); }
+    { load_pair<C, RAW>(rs, qf, qr, pt, gl, ref8, q8, qb); }
+    template <bool RAW>
     __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C], int T_end,
                                 int tB, uint32_t *wsA, uint32_t *wsB)
-    { dp_pass_p16<C>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    { dp_pass_p16<C, false, RAW>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
     // start cell (R, Q) of the traceback: lane, column in lane, stored step (tB_tile = tile's own first stored step)
     __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
     { l = (Q - 1) / C; c = (Q - 1) - l * C; k = R + l - tB_tile; }
@@ -438,7 +464,8 @@ template <int C> struct UniformLayout {
 
 // ---------------------------------------------------------------------------
 // Persistent main kernel: every group carries two candidates (slot A / slot B).
-template <class L>
+// RAW: the sets hold bytes other than ACGT and are compared as raw bytes (see dp_pass_p16).
+template <class L, bool RAW>
 __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
@@ -457,7 +484,6 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
     const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (L::kRow0 - 1 - w.gl);
     uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
     uint32_t *wsB = wsA + kp.ws_words;
-    const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
 
     ChainState *st = chain_lds[group_in_block];
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
@@ -526,7 +552,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
 
         GACT_STAMP(t_b);
         uint32_t qb[L::kSlotsPerLane];
-        L::load(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
+        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb);
         wave_sync();
         GACT_STAMP(t_c);
 
@@ -539,7 +565,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
         if (wave_longest > kp.prio_bases[1]) __builtin_amdgcn_s_setprio(2);
         else if (wave_longest > kp.prio_bases[0]) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
-        L::pass(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
+        L::template pass<RAW>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
         __builtin_amdgcn_s_setprio(3);
         GACT_STAMP(t_d);
 
@@ -599,7 +625,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
 // whole tile), two candidates per group, then the chain is handed to the main launch
 // (ChainQueues) exactly as the int32 seed launch does (extend_kernel, seed_mode).
 // Needs p16_argmax_ok on top of p16_scoring_ok.
-template <int C>
+template <int C, bool RAW>
 __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     const gact_candidate *__restrict__ cands, int first_cand, int n, int rc_from,
@@ -620,7 +646,6 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
     const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (L::kRow0 - 1 - w.gl);
     uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
     uint32_t *wsB = wsA + kp.ws_words;
-    const bool raw = refs.use_raw | qfwd.use_raw | qrc.use_raw;
 
     ChainState *st = chain_lds[group_in_block];
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; st[w.gl].comp = 0; }
@@ -667,12 +692,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
         const int T_end = wave_max4(imax(L::last_step(pt.R[0], pt.Q[0]), L::last_step(pt.R[1], pt.Q[1])));
 
         uint32_t qb[C];
-        L::load(refs, qfwd, qrc, raw, pt, w.gl, ref8, q8, qb);
+        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb);
         wave_sync();
 
         P16Best pb;
         __builtin_amdgcn_s_setprio(0);
-        dp_pass_p16<C, true>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, RQ, &pb);
+        dp_pass_p16<C, true, RAW>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, RQ, &pb);
         __builtin_amdgcn_s_setprio(3);
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pointer stores -> L2 before the sc1 loads

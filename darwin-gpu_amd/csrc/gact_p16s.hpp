@@ -65,7 +65,7 @@ template <int C2> __device__ __forceinline__ int split_first_pointer_step(int R,
 
 // ---------------------------------------------------------------------------
 // ref16[t] / ref16[t - 16] hold the bases of region 1's / region 2's row at step t.
-template <int C1, int C2>
+template <int C1, int C2, bool RAW = true>
 __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
                                              const uint16_t *__restrict__ ref16,
                                              const uint32_t (&qb)[C1 + C2],
@@ -75,22 +75,30 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
     constexpr int CT = C1 + C2;
     constexpr int QD = (C2 + 3) / 4;
     constexpr int LAG = kGroup;
-    uint32_t Hm[CT], Mo[CT], Iup[CT];       // H+match, M+open, I of the previous row (both tiles)
+    const uint32_t hbias = RAW ? kc.match : kc.mism;        // substitution score forms: see dp_pass_p16
+    uint32_t Hm[CT], Mo[CT], Iup[CT];       // H+bias, M+open, I of the previous row (both tiles)
     uint32_t accO[QD * 4], accF[QD * 4];    // pointer bits of the region-2 slots (see dp_pass_p16)
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-        Hm[c] = kc.match; Mo[c] = kc.open; Iup[c] = kc.ninf;
+        Hm[c] = hbias; Mo[c] = kc.open; Iup[c] = kc.ninf;
     }
 #pragma unroll
     for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
     // last slot of each region as the neighbour lane will see it
-    uint32_t Mo1 = kc.open, D1 = kc.ninf, H1 = kc.match;
-    uint32_t Mo2 = kc.open, D2 = kc.ninf, H2 = kc.match;
-    uint32_t Hdiag1 = kc.match, Hdiag2 = kc.match;
-    uint32_t Ml1 = kc.open, Dl1 = kc.ninf, Hl1 = kc.match;      // what lane gl-1 shows; lane 0 keeps the border
+    uint32_t Mo1 = kc.open, D1 = kc.ninf, H1 = hbias;
+    uint32_t Mo2 = kc.open, D2 = kc.ninf, H2 = hbias;
+    uint32_t Hdiag1 = hbias, Hdiag2 = hbias;
+    uint32_t Ml1 = kc.open, Dl1 = kc.ninf, Hl1 = hbias;         // what lane gl-1 shows; lane 0 keeps the border
 
     auto unpack = [](uint32_t w) { return __builtin_amdgcn_perm(0u, w, 0x0c010c00u); };      // {byte 1, byte 0} -> two half-words
-    uint32_t rb1 = unpack(ref16[1]), rb2 = unpack(ref16[1 - LAG]);
+    auto lut = [&](uint32_t amount) { return kc.dsub >> (amount & 31u); };
+    // per region: RAW the two ref bases as half-words (a), else the two tiles' look-up words (a, b)
+    uint32_t rb1 = 0, rb1b = 0, rb2 = 0, rb2b = 0;
+    auto set_rows = [&](uint32_t w1, uint32_t w2) {
+        if (RAW) { rb1 = unpack(w1); rb2 = unpack(w2); }
+        else { rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8); }
+    };
+    set_rows(ref16[1], ref16[1 - LAG]);
 
     auto step = [&](const int t, auto ptr_tag) {
         constexpr bool PTR = decltype(ptr_tag)::value;
@@ -114,8 +122,9 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
 #pragma unroll
         for (int c = 0; c < CT; c++) {
             if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            const uint32_t neq = pk_min1(qb[c] ^ (c < C1 ? rb1 : rb2));        // align.cpp:134
-            const uint32_t Mx = pk_mad_s(neq, kc.nd, Hd);
+            uint32_t Mx;                                                        // align.cpp:134
+            if (RAW) Mx = pk_mad_s(pk_min1(qb[c] ^ (c < C1 ? rb1 : rb2)), kc.nd, Hd);
+            else Mx = pk_add(Hd, __builtin_amdgcn_perm(c < C1 ? rb1b : rb2b, c < C1 ? rb1 : rb2, qb[c]));
             Hd = Hm[c];
             M[c] = pk_max0(Mx);                                                 // :145-147
             const uint32_t Ie = pk_add_s(Iup[c], kc.ext);                       // :150
@@ -141,13 +150,12 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
                 const uint32_t o = pk_mad_vvv(na, nb, na);
                 accO[c - C1] = pk_shl_add4(accO[c - C1], pk_mad_vvv(nz, o, nz));
             }
-            Hm[c] = pk_add_s(H, kc.match);
+            Hm[c] = pk_add_s(H, hbias);
             Ml = Mo[c];
             Dl = D;
         }
         Mo2 = Ml; D2 = Dl; H2 = Hm[CT - 1];
-        rb1 = unpack(w1);
-        rb2 = unpack(w2);
+        set_rows(w1, w2);
     };
 
     auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
@@ -188,36 +196,32 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
 // ---------------------------------------------------------------------------
 // Column slot s of lane gl holds padded column p (1..16*CT, columns right-aligned:
 // DP column j = p - (16*CT - Q), p <= 0 .. are pads).
-template <int C1, int C2>
+template <int C1, int C2, bool RAW>
 __device__ __forceinline__ void load_pair_split(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc,
-                                                bool raw, const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8,
+                                                const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8,
                                                 uint32_t (&qb)[C1 + C2])
 {
     using G = GeometrySplit<C1, C2>;
     constexpr int CT = C1 + C2;
     uint32_t *ref32 = reinterpret_cast<uint32_t *>(ref8);
-    for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = 0xffffffffu;
+    for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = RAW ? 0xffffffffu : kLutPadRow * 0x01010101u;
     wave_sync();
     uint32_t rv[kSlots][CT], qv[kSlots][CT];
     int dq[kSlots][CT];
-    auto issue = [&](auto raw_tag) {
-        constexpr bool RAW = decltype(raw_tag)::value;
 #pragma unroll
-        for (int h = 0; h < kSlots; h++) {
-            const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
-            const int S = G::kTileMax - pt.Q[h];
+    for (int h = 0; h < kSlots; h++) {
+        const SeqSetDev &qs = pt.comp[h] ? qrc : qfwd;
+        const int S = G::kTileMax - pt.Q[h];
 #pragma unroll
-            for (int s = 0; s < CT; s++) {
-                const int p = (s < C1) ? gl * C1 + s + 1 : G::W1 + gl * C2 + (s - C1) + 1;
-                dq[h][s] = p - S - 1;                                      // 0-based DP column, < 0 = left pad
-                rv[h][s] = fetch_base<RAW>(rs, slice_pos(pt.rp0[h], pt.R[h], pt.reverse[h], gl * CT + s));
-                qv[h][s] = fetch_base<RAW>(qs, slice_pos(pt.qp0[h], pt.Q[h], pt.reverse[h], imax(dq[h][s], 0)));
-            }
+        for (int s = 0; s < CT; s++) {
+            const int p = (s < C1) ? gl * C1 + s + 1 : G::W1 + gl * C2 + (s - C1) + 1;
+            dq[h][s] = p - S - 1;                                      // 0-based DP column, < 0 = left pad
+            rv[h][s] = fetch_base<RAW>(rs, slice_pos(pt.rp0[h], pt.R[h], pt.reverse[h], gl * CT + s));
+            qv[h][s] = fetch_base<RAW>(qs, slice_pos(pt.qp0[h], pt.Q[h], pt.reverse[h], imax(dq[h][s], 0)));
         }
-    };
-    if (raw) issue(std::true_type{}); else issue(std::false_type{});
+    }
 #pragma unroll
-    for (int s = 0; s < CT; s++) qb[s] = 0;
+    for (int s = 0; s < CT; s++) qb[s] = RAW ? 0u : kPermZero * 0x01010101u;
 #pragma unroll
     for (int h = 0; h < kSlots; h++) {
         const int R = pt.R[h];
@@ -225,11 +229,19 @@ __device__ __forceinline__ void load_pair_split(const SeqSetDev &rs, const SeqSe
 #pragma unroll
         for (int s = 0; s < CT; s++) {
             const int d = gl * CT + s;                                     // DP row handled by this slot of the loader
-            if (d < R) rrow[d * 2] = (uint8_t)rv[h][s];
             const bool real = dq[h][s] >= 0;
-            const uint32_t qcode = real ? qv[h][s] : kQueryPad;
-            if (real) q8[h * G::kTileMax + dq[h][s]] = (uint8_t)qcode;
-            qb[s] |= qcode << (16 * h);
+            if (RAW) {
+                if (d < R) rrow[d * 2] = (uint8_t)rv[h][s];
+                const uint32_t qcode = real ? qv[h][s] : kQueryPad;
+                if (real) q8[h * G::kTileMax + dq[h][s]] = (uint8_t)qcode;
+                qb[s] |= qcode << (16 * h);
+            } else {                                                       // LUT form, see load_pair
+                if (d < R) rrow[d * 2] = (uint8_t)(24u - rv[h][s] * 8u);
+                if (real) {
+                    q8[h * G::kTileMax + dq[h][s]] = (uint8_t)(24u - qv[h][s] * 8u);
+                    qb[s] = (qb[s] & ~(0xffu << (16 * h))) | ((qv[h][s] + 4u * h) << (16 * h));
+                }
+            }
         }
     }
 }
@@ -243,12 +255,14 @@ template <int C1, int C2> struct SplitLayout {
     static constexpr int kRow0 = G::kRow0;
     __device__ static int last_step(int R, int Q) { return split_last_step<C2>(R, Q); }
     __device__ static int first_pointer_step(int R, int Q, int early) { return split_first_pointer_step<C2>(R, Q, early); }
-    __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr, bool raw,
+    template <bool RAW>
+    __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr,
                                 const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C1 + C2])
-    { load_pair_split<C1, C2>(rs, qf, qr, raw, pt, gl, ref8, q8, qb); }
+    { load_pair_split<C1, C2, RAW>(rs, qf, qr, pt, gl, ref8, q8, qb); }
+    template <bool RAW>
     __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
                                 int T_end, int tB, uint32_t *wsA, uint32_t *wsB)
-    { dp_pass_p16s<C1, C2>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    { dp_pass_p16s<C1, C2, RAW>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
     // the start cell (R, Q) is the last column of region 2: lane 15, slot C2-1
     __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
     { (void)Q; l = kGroup - 1; c = C2 - 1; k = R + (kGroup - 1) - tB_tile; }

@@ -31,6 +31,9 @@ BODY(k_sdwa_cmp2, uint64_t m; asm volatile("v_cmp_ge_i16_sdwa %1, %0, %2 src0_se
 BODY(k_cmp2, uint64_t m; asm volatile("v_cmp_ge_i32 %1, %0, %2\n\tv_cmp_eq_u32 %1, %0, %2" : "+v"(a[k]), "=&s"(m) : "v"(inc)); z ^= (uint32_t)m;)
 BODY(k_addc2, asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(a[k]) : "v"(inc) : "vcc");)
 BODY(k_max3_dpp, asm volatile("v_max3_i32 %0, %0, %1, %2\n\tv_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[k]) : "v"(inc), "v"(seed));)
+BODY(k_perm2, asm volatile("v_perm_b32 %0, %0, %1, %2\n\tv_perm_b32 %0, %1, %0, %2" : "+v"(a[k]) : "v"(inc), "v"(seed));)
+BODY(k_perm_add, asm volatile("v_perm_b32 %0, %0, %1, %2\n\tv_pk_add_i16 %0, %0, %1" : "+v"(a[k]) : "v"(inc), "v"(seed));)
+BODY(k_lshr_bfe, asm volatile("v_lshrrev_b32 %0, %1, %0\n\tv_bfe_u32 %0, %0, %1, 2" : "+v"(a[k]) : "v"(inc), "v"(seed));)
 BODY(k_cndmask, asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_cmp_eq_u32 vcc, %0, %2" : "+v"(a[k]) : "v"(inc), "v"(seed) : "vcc");)
 
 template <class K> void run(const char *name, K kern, int waves_per_simd)
@@ -57,7 +60,7 @@ template <class K> void run(const char *name, K kern, int waves_per_simd)
 
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2, 3, 4, 8}) {
         run("add_max", k_add_max, w);
         run("pk_add_max", k_pk_add_max, w);
         run("pk_add_sgpr", k_pk_add_s, w);
@@ -70,6 +73,9 @@ int main()
         run("addc2", k_addc2, w);
         run("max3_dpp", k_max3_dpp, w);
         run("cndmask_cmp", k_cndmask, w);
+        run("perm2", k_perm2, w);
+        run("perm_pk_add", k_perm_add, w);
+        run("lshr_bfe", k_lshr_bfe, w);
         printf("\n");
     }
     return 0;

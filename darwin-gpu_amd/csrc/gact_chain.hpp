@@ -280,11 +280,17 @@ __device__ __forceinline__ void chain_advance(ChainState &s, bool stop, const Sc
 }
 
 // device-side bookkeeping shared by the seed and the main launch.  The seed launch
-// files every candidate it hands off under its estimated remaining chain length
-// (kBuckets classes of kBucketTiles tiles); the main launch pops the longest
-// class first, so the tail of the launch consists of short chains only.
-constexpr int kBuckets = 16;
-constexpr int kBucketTiles = 8;
+// files every candidate it hands off under its estimated remaining chain length;
+// the main launch pops the longest class first.  Once the queues are empty the
+// launch lasts as long as the chains popped last, so the classes are one tile
+// wide at the short end (measured with 16 classes of 8 tiles: queues empty at
+// 61 ms, last wave done at 73 ms) and coarser where only the order matters:
+// 0..15 tiles one class each, 16..47 in fours, 48..111 in eights, longer in one.
+constexpr int kBuckets = 32;
+__host__ __device__ constexpr int length_class(int tiles)      // ascending with the length, 0 .. kBuckets-1
+{
+    return tiles < 16 ? (tiles < 0 ? 0 : tiles) : tiles < 48 ? 16 + (tiles - 16) / 4 : tiles < 112 ? 24 + (tiles - 48) / 8 : 31;
+}
 struct ChainQueues {
     int *pop_seed;               // next candidate index for the seed launch
     int *bucket_count;           // [kBuckets] candidates handed to the main launch, bucket 0 = longest
@@ -307,7 +313,7 @@ __device__ __forceinline__ int chain_remaining(const ChainState &s)
 __device__ __forceinline__ int chain_bucket(const ChainState &s, const KParams &kp)
 {
     const int tiles = chain_remaining(s) / imax(kp.early, 1);
-    return imax(0, kBuckets - 1 - tiles / kBucketTiles);
+    return kBuckets - 1 - length_class(tiles);
 }
 
 }  // namespace gact

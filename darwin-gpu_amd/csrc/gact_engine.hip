@@ -1057,6 +1057,16 @@ int gact_hip_candidates_download(gact_hip_engine *e, int slot, int32_t n, gact_c
 }
 
 #ifdef GACT_STAMPS
+// diagnostic build: per-wave (start, queues empty, end, iterations) of the last main launch
+int gact_hip_debug_timeline(gact_hip_engine *e, unsigned long long *out, int n_waves)
+{
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(gact::g_timeline), (size_t)std::min(n_waves, 4096) * 4 * sizeof(unsigned long long)));
+    return 0;
+}
+
 // diagnostic build: read and clear the per-phase clock totals of extend_p16_kernel
 int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
 {

@@ -24,6 +24,8 @@ namespace gact {
 #ifdef GACT_STAMPS
 __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_stamps2[8];
+// per wave of the main launch: start, first time it found the queues empty, end (s_memrealtime, 100 MHz), iterations
+__device__ unsigned long long g_timeline[4 * 4096];
 #define GACT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #define GACT_ACC(slot, t0, t1) stamp_acc[slot] += (t1) - (t0)
 #else
@@ -493,6 +495,8 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
     __builtin_amdgcn_s_setprio(3);
 #ifdef GACT_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl_empty = 0;
 #endif
 
     for (;;) {
@@ -522,7 +526,13 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
                         }
                         my_bucket++;
                     }
-                    if (cand < 0) { exhausted = true; break; }
+                    if (cand < 0) {
+                        exhausted = true;
+#ifdef GACT_STAMPS
+                        if (!tl_empty) tl_empty = __builtin_amdgcn_s_memrealtime();
+#endif
+                        break;
+                    }
                     s = cq.states[cand];
                 }
                 pk = chain_pick(s, kp, same_file, out, w.gl == 0);
@@ -615,8 +625,14 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
 #endif
     }
 #ifdef GACT_STAMPS
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < 8; k++) atomicAdd(&g_stamps[k], stamp_acc[k]);
+        const int wv = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        if (wv < 4096) {
+            g_timeline[4 * wv] = tl_start; g_timeline[4 * wv + 1] = tl_empty;
+            g_timeline[4 * wv + 2] = __builtin_amdgcn_s_memrealtime(); g_timeline[4 * wv + 3] = stamp_acc[6];
+        }
+    }
 #endif
 }
 

@@ -299,7 +299,26 @@ struct ChainQueues {
     int *live;                   // [kBuckets][live_stride] candidate ids handed off
     int live_stride;
     ChainState *states;          // their chain states
+    int *longest_now;            // [kEpochs] longest remaining chain (bases) any wave reported, per time slice
 };
+
+// The main launch's waves rank themselves against the longest chain still running anywhere: every wave posts
+// its longest remaining chain into the slice of the 100 MHz clock it is in and reads the previous slice
+// (complete) and the current one (so far).  Slices are 1.3 ms, the ring covers 84 ms and is recycled two
+// slices ahead.
+constexpr int kEpochs = 64;
+__device__ __forceinline__ int longest_running(const ChainQueues &cq, int mine, bool writer)
+{
+    const unsigned e = (unsigned)(__builtin_amdgcn_s_memrealtime() >> 17);
+    int ref = mine;
+    if (writer) {
+        atomicMax(&cq.longest_now[e % kEpochs], mine);
+        cq.longest_now[(e + 2) % kEpochs] = 0;
+        ref = imax(__hip_atomic_load(&cq.longest_now[(e + kEpochs - 1) % kEpochs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                   __hip_atomic_load(&cq.longest_now[e % kEpochs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    return ref;
+}
 
 // bases this chain still has to cover, roughly (each tile advances ~early of them)
 __device__ __forceinline__ int chain_remaining(const ChainState &s)

@@ -48,7 +48,8 @@ struct KParams {
     int32_t match, mismatch, open, ext;
     int32_t thr;
     int32_t ws_words;         // workspace dwords per group
-    int32_t prio_bases[2];    // main launch: chains with more bases left than this run their DP at priority 1 / 2
+    int32_t prio_bases[2];    // main launch: chains with more bases left than this run their DP at priority 1 / 2;
+                              // {0, 0}: rank against the longest chain running right now instead (longest_running)
 };
 
 template <int C> struct Geometry {

@@ -267,7 +267,7 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
 
 // d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [8..8+kBuckets) bucket_count,
 // [8+kBuckets..8+2*kBuckets) bucket_pop
-constexpr int kCounterInts = 8 + 2 * gact::kBuckets;
+constexpr int kCounterInts = 8 + 2 * gact::kBuckets + gact::kEpochs;
 
 gact::ChainQueues queues(Slot &sl)
 {
@@ -279,6 +279,7 @@ gact::ChainQueues queues(Slot &sl)
     q.live = sl.live.p;
     q.live_stride = (int)(sl.live.cap / gact::kBuckets);
     q.states = sl.chain_states.p;
+    q.longest_now = sl.d_counter + 8 + 2 * gact::kBuckets;
     return q;
 }
 
@@ -299,8 +300,11 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     // DP issue priority by remaining chain length (extend_p16_kernel): thirds of the longest possible chain
     gact::KParams kp = e->kp;
     const int64_t longest = std::min(rs.max_len, std::max(need_f ? qf.max_len : 0, need_r ? qr.max_len : 0));
-    kp.prio_bases[0] = e->chain_prio ? (int32_t)std::min<int64_t>(longest / 3, 0x7fffffff) : 0x7fffffff;
-    kp.prio_bases[1] = e->chain_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : 0x7fffffff;
+    // GACT_HIP_STATIC_PRIO: thirds of the longest possible chain instead of the ranking against what is running
+    const bool static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
+    kp.prio_bases[0] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(longest / 3, 0x7fffffff) : 0;
+    const int rank16 = (12 << 8) | 8;                // above 3/4 of the longest running chain: priority 2, above 1/2: 1
+    kp.prio_bases[1] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : rank16;
     // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
     if (e->seed16) {
         const int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));

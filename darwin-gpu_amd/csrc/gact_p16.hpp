@@ -572,8 +572,14 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
         // ... and among the DP passes, the waves that carry the longest chains go first: when there are
         // fewer chains than tile slots the launch lasts as long as its longest chain
         const int wave_longest = wave_max4(longest);
-        if (wave_longest > kp.prio_bases[1]) __builtin_amdgcn_s_setprio(2);
-        else if (wave_longest > kp.prio_bases[0]) __builtin_amdgcn_s_setprio(1);
+        const int ref_longest = __builtin_amdgcn_readfirstlane(longest_running(cq, wave_longest, (threadIdx.x & 63) == 0));
+        // ranking mode (prio_bases[0] == 0): prio_bases[1] = thresholds in sixteenths of the longest, hi << 8 | mid
+        const bool rank_hi = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] >> 8) * ref_longest
+                                                   : wave_longest > kp.prio_bases[1];
+        const bool rank_mid = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] & 255) * ref_longest
+                                                    : wave_longest > kp.prio_bases[0];
+        if (rank_hi) __builtin_amdgcn_s_setprio(2);
+        else if (rank_mid) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
         L::template pass<RAW>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
         __builtin_amdgcn_s_setprio(3);

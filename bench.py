@@ -135,9 +135,11 @@ def main():
 
     kernel_ms = []
 
+    rec_buf = np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE)      # the job's output buffer, owned by the caller
+
     def step(record_ms=False):
         eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=0)
-        rec = eng.candidates_fetch(nf + nr, slot=0)
+        rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
         rf, rr = rec[:nf], rec[nf:]
         if record_ms:
             kernel_ms.append(eng.last_run_stats(0))

@@ -275,8 +275,11 @@ class Engine:
         """candidates [first, first+n) of the uploaded array; index >= rc_from => complement"""
         self._check(self.L.gact_hip_candidates_run_mixed(self.h, slot, first, n, rc_from, int(same_file)))
 
-    def candidates_fetch(self, n, slot=0):
-        out = np.zeros(n, dtype=OVERLAP_DTYPE)
+    def candidates_fetch(self, n, slot=0, out=None):
+        """records of candidates [0, n); `out`: a caller-owned OVERLAP_DTYPE array to fill (no allocation)"""
+        if out is None:
+            out = np.empty(n, dtype=OVERLAP_DTYPE)
+        assert out.dtype == OVERLAP_DTYPE and len(out) >= n and out.flags["C_CONTIGUOUS"]
         self._check(self.L.gact_hip_candidates_fetch(self.h, slot, n, out.ctypes.data))
         return out
 

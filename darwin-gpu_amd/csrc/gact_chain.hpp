@@ -235,7 +235,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         n_ext += gprev & g;
         n_open += (gprev ^ g) & (left ? gprev : g);
         n_m += !g;
-        n_eq += !g & eq;
+        n_eq += (!g) & eq;
         gprev = g;
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
         nis -= cur != 3;

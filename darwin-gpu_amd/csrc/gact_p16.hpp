@@ -448,6 +448,7 @@ template <int C> struct UniformLayout {
     static constexpr int kSlotsPerLane = C;
     static constexpr int kWalkCols = C, kWalkQuads = C / 4;       // columns / stored quads per lane for the walker
     static constexpr int kRow0 = kGroup;                          // ref stream entry of (delay 0, row 1)
+    static constexpr int kBlocksPerCu = C <= 20 ? 3 : 1;          // register budget: 32 columns per lane need a whole SIMD's file
     __device__ static int last_step(int R, int Q) { return gact::last_step<C>(R, Q); }
     __device__ static int first_pointer_step(int R, int Q, int early) { return gact::first_pointer_step<C>(R, Q, early, false); }
     template <bool RAW>
@@ -468,7 +469,7 @@ template <int C> struct UniformLayout {
 // Persistent main kernel: every group carries two candidates (slot A / slot B).
 // RAW: the sets hold bytes other than ACGT and are compared as raw bytes (see dp_pass_p16).
 template <class L, bool RAW>
-__global__ __launch_bounds__(kBlockThreads, 3) void extend_p16_kernel(
+__global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
     uint32_t *__restrict__ ws_all)

@@ -253,6 +253,7 @@ template <int C1, int C2> struct SplitLayout {
     static constexpr int kSlotsPerLane = C1 + C2;
     static constexpr int kWalkCols = C2, kWalkQuads = G::kQuads;
     static constexpr int kRow0 = G::kRow0;
+    static constexpr int kBlocksPerCu = 3;
     __device__ static int last_step(int R, int Q) { return split_last_step<C2>(R, Q); }
     __device__ static int first_pointer_step(int R, int Q, int early) { return split_first_pointer_step<C2>(R, Q, early); }
     template <bool RAW>

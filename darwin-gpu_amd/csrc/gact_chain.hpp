@@ -191,25 +191,27 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     const bool left = phase == 0;
     const int p0 = l0 * CW + c0, kA = k0 - l0;
-    const int lim_i = imin(early, R), lim_j = imin(early, Q);
+    const int nlim_i = -imin(early, R), nlim_j = -imin(early, Q);
     const uint8_t *ra = rrow + (R - 1) * rstride;
     const uint8_t *qa = qrow + (Q - 1);
     int nis = 0, njs = 0;                                       // minus the ref / query steps taken
     int n_ext = 0, n_open = 0, n_eq = 0, n_m = 0;
     uint32_t cur = 0, fl = 0;                                   // state (op-code numbering), flags of the current cell
     TbRegion<CW> rg;
-    int off0 = 0, off1 = 0;
+    int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
         tb_refill_at<CW, QN>(ws, scratch, l, c, k, rg);
-        off0 = -12 * rg.fbase[0] - 4 * rg.qbase0;
-        off1 = 24 - 12 * rg.fbase[1] - 4 * (QN - 3);
+        off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
+        off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
     };
     // 32-bit LDS addressing (through the generic pointer the index arithmetic is done in 64 bits)
+    typedef __attribute__((address_space(3))) const uint8_t LdsByte;
     typedef __attribute__((address_space(3))) const uint32_t LdsWord;
-    LdsWord *cache = (LdsWord *)scratch;
+    LdsByte *cache = (LdsByte *)scratch;
     auto fetch = [&](int l, int c, int k, uint32_t &code, uint32_t &flags) {
-        const uint32_t w = cache[c + (int)__umul24((uint32_t)k >> 3, 12u) + (l == rg.l0 ? off0 : off1)];
+        const uint32_t at = (uint32_t)(4 * c + (int)__umul24((uint32_t)k >> 3, 48u) + (l == rg.l0 ? off0 : off1));
+        const uint32_t w = *(LdsWord *)(cache + at);
         if (FMT == 1) {
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
@@ -227,20 +229,23 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         fetch(l0, c0, k0, cur, fl);
     }
     if (left && !wk.have_left && cur != 0) { wk.have_left = 1; wk.left_first_gap = cur != 1; }
-    int gprev = left ? wk.pend_gap : !wk.open_flag;
+    // conditions live as lane masks on the scalar unit; a counter takes one as the carry of a single VALU op
+    const uint64_t left_m = lanes(left);
+    uint64_t gprev = lanes(left ? wk.pend_gap != 0 : wk.open_flag == 0);
     for (int it = 0; cur != 0; it++) {
         // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209)
-        const int g = cur != 1;
-        const int eq = ra[nis * rstride] == qa[njs];
-        n_ext += gprev & g;
-        n_open += (gprev ^ g) & (left ? gprev : g);
-        n_m += !g;
-        n_eq += (!g) & eq;
-        gprev = g;
+        const uint64_t g = lanes(cur != 1);
+        const uint64_t eq = lanes(ra[nis * rstride] == qa[njs]);
+        n_ext = add_lane_bit(n_ext, gprev & g);
+        n_open = add_lane_bit(n_open, (gprev ^ g) & ((left_m & gprev) | (~left_m & g)));
+        n_m = add_lane_bit(n_m, ~g);
+        n_eq = add_lane_bit(n_eq, ~g & eq);
+        gprev = (gprev & ~lanes(true)) | g;                       // walkers that have stopped keep their last column
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
-        nis -= cur != 3;
-        njs -= cur != 2;
+        nis = sub_lane_bit(nis, lanes(cur != 3));
+        njs = sub_lane_bit(njs, lanes(cur != 2));
         const uint32_t forced = (fl & (4u - cur)) ? cur : 1u;
+        // (a walker that is about to stop may have left the tile: keep its addresses inside the stored window)
         const int p = imax(p0 + njs, 0);
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
         const int c = p + __mul24(l, -CW);
@@ -249,12 +254,13 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         uint32_t code;
         fetch(l, c, k, code, fl);
         const uint32_t nxt = cur == 1 ? code : forced;
-        cur = (-nis >= lim_i || -njs >= lim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
+        cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
     }
     ref_steps = -nis; query_steps = -njs; nst = -nis - njs - n_m;
     wk.score += n_ext * kp.ext + n_open * kp.open + n_eq * kp.match + (n_m - n_eq) * kp.mismatch;
-    wk.pend_gap = left ? gprev : wk.pend_gap;
-    wk.open_flag = left ? wk.open_flag : !gprev;
+    const bool last_gap = (gprev >> (threadIdx.x & 63)) & 1;
+    wk.pend_gap = left ? (int)last_gap : wk.pend_gap;
+    wk.open_flag = left ? wk.open_flag : (int)!last_gap;
 }
 
 // after the traceback (gact.cpp:111-133 / :172-194); src = lane holding the walk's results

@@ -82,6 +82,21 @@ __device__ __forceinline__ uint32_t shl1_insert(uint32_t x, uint64_t lane_mask)
     return r;
 }
 __device__ __forceinline__ uint64_t lanes(bool cond) { return __builtin_amdgcn_ballot_w64(cond); }
+// x + bit(lane) / x - bit(lane) in one VALU op (same wait states as shl1_insert)
+__device__ __forceinline__ int add_lane_bit(int x, uint64_t lane_mask)
+{
+    int r;
+    uint64_t carry_out;
+    asm("s_nop 1\n\tv_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(lane_mask));
+    return r;
+}
+__device__ __forceinline__ int sub_lane_bit(int x, uint64_t lane_mask)
+{
+    int r;
+    uint64_t carry_out;
+    asm("s_nop 1\n\tv_subb_co_u32 %0, %1, %2, 0, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(lane_mask));
+    return r;
+}
 
 __device__ __forceinline__ void wave_sync()
 {

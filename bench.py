@@ -68,8 +68,8 @@ def pmc_traffic(workload_name, candidates, kernel, cells):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ecoli10x")
     ap.add_argument("--candidates", default="dsoft", choices=["dsoft", "synthetic"],
                     help="dsoft: candidates from the D-SOFT filter itself; synthetic: placed from simulator truth")

@@ -182,7 +182,7 @@ struct ScoreWalk {
 // rrow/qrow point at the LDS byte of DP row 1 / column 1; rstride is the ref stream's
 // byte stride.  (l0, c0, k0) = lane, column-in-lane and stored step of the start cell
 // (R, Q) in the pass's layout; CW columns per lane, QN column quads stored per lane.
-template <int CW, int FMT, int QN = CW / 4>
+template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
@@ -201,7 +201,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
-        tb_refill_at<CW, QN>(ws, scratch, l, c, k, rg);
+        tb_refill_at<CW, QN, LANES>(ws, scratch, l, c, k, rg);
         off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
     };
@@ -264,17 +264,18 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
 }
 
 // after the traceback (gact.cpp:111-133 / :172-194); src = lane holding the walk's results
+template <int LANES = kGroup>
 __device__ __forceinline__ void chain_advance(ChainState &s, bool stop, const ScoreWalk &wk, int ref_steps,
                                               int query_steps, int nst, int src)
 {
-    ref_steps = __shfl(ref_steps, src, kGroup);
-    query_steps = __shfl(query_steps, src, kGroup);
-    nst = __shfl(nst, src, kGroup);
-    s.score = __shfl(wk.score, src, kGroup);
-    s.pend_gap = __shfl(wk.pend_gap, src, kGroup);
-    s.open_flag = __shfl(wk.open_flag, src, kGroup);
-    s.have_left = __shfl(wk.have_left, src, kGroup);
-    s.left_first_gap = __shfl(wk.left_first_gap, src, kGroup);
+    ref_steps = __shfl(ref_steps, src, LANES);
+    query_steps = __shfl(query_steps, src, LANES);
+    nst = __shfl(nst, src, LANES);
+    s.score = __shfl(wk.score, src, LANES);
+    s.pend_gap = __shfl(wk.pend_gap, src, LANES);
+    s.open_flag = __shfl(wk.open_flag, src, LANES);
+    s.have_left = __shfl(wk.have_left, src, LANES);
+    s.left_first_gap = __shfl(wk.left_first_gap, src, LANES);
     if (nst > 0) s.first_tile = 0;                                   // :112 / :173
     s.i = query_steps; s.j = ref_steps;                              // gact.cpp's i counts query bases
     if (!stop) {

@@ -121,6 +121,23 @@ __device__ __forceinline__ int wave_min4(int v)
 {
     return imin(imin(group_value(v, 0), group_value(v, 1)), imin(group_value(v, 2), group_value(v, 3)));
 }
+// the same for a wave cut into groups of LANES lanes (16: four groups, 32: two); v is group-uniform
+template <int LANES> __device__ __forceinline__ int wave_max_groups(int v)
+{
+    return LANES == 32 ? imax(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32)) : wave_max4(v);
+}
+template <int LANES> __device__ __forceinline__ int wave_min_groups(int v)
+{
+    return LANES == 32 ? imin(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 32)) : wave_min4(v);
+}
+// lane n reads lane n-1 across the two DPP rows of a 32-lane group: lane 16 (48) takes lane 15 (47) from a
+// row_bcast:15 into the odd rows, then row_shr:1 overwrites every lane but the first of each row; lane 0 (32)
+// keeps `old` (tools/dpp_probe.hip)
+__device__ __forceinline__ int dpp_shr1_32(int v, int old)
+{
+    const int x = __builtin_amdgcn_update_dpp(old, v, 0x142, 0xA, 0xF, false);
+    return __builtin_amdgcn_update_dpp(x, v, 0x111, 0xF, 0xF, false);
+}
 
 // one base of a resident set at concat position pos
 template <bool RAW>
@@ -426,7 +443,7 @@ template <int CW> struct TbRegion {
 
 // anchor cell given as (lane l0, column-in-lane c0, stored step k0 = i + l0 - tB)
 // CW = columns per lane, QN = 16-byte column quads stored per lane and flush block
-template <int CW, int QN = CW / 4>
+template <int CW, int QN = CW / 4, int LANES = kGroup>
 __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
                                              TbRegion<CW> &rg)
 {
@@ -445,7 +462,7 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
         for (int lev = 0; lev < 2; lev++)
 #pragma unroll
             for (int qq = 0; qq < 3; qq++)
-                addr[(sl * 2 + lev) * 3 + qq] = base + ((fb + lev) * QN + imin(qb + qq, QN - 1)) * kGroup + lane;
+                addr[(sl * 2 + lev) * 3 + qq] = base + ((fb + lev) * QN + imin(qb + qq, QN - 1)) * LANES + lane;
     }
     u32x4 r[12];
 #pragma unroll

@@ -100,7 +100,7 @@ template <class T> struct DevBuf {
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
-    bool timed = false, two_phase = false;
+    bool timed = false, two_phase = false, wide = false;
     DevBuf<gact_tile> tiles;
     DevBuf<gact_tile_result> results;
     DevBuf<uint8_t> states;
@@ -162,6 +162,7 @@ struct gact_hip_engine {
     int C = 20;                 // columns per lane
     bool p16 = false;           // scoring fits the packed-int16 main kernel
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
+    int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
@@ -323,12 +324,20 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     sl.two_phase = e->p16;
     if (e->p16) {
         HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
-        auto km = e->split ? (raw ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
+        // fewer chains than the narrow layouts have tile slots: the launch lasts as long as its longest chain, so
+        // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
+        const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
+        sl.wide = C == 20 && e->wide >= 0 && (e->wide > 0 || n <= narrow_slots);
+        auto km = sl.wide  ? (raw ? gact::extend_p16_kernel<gact::WideLayout, true>
+                                  : gact::extend_p16_kernel<gact::WideLayout, false>)
+                : e->split ? (raw ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
                                   : gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>)
                            : (raw ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
                                   : gact::extend_p16_kernel<gact::UniformLayout<C>, false>);
-        hipLaunchKernelGGL(km, dim3(main_blocks), dim3(gact::kBlockThreads), 0, sl.stream, kp, e->kc, rs.dev(raw),
-                           qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file, sl.overlaps.p, queues(sl), sl.d_ws);
+        const int wide_blocks = std::max(1, std::min((n + 15) / 16, e->grid_blocks));      // 4 tiles per wave
+        hipLaunchKernelGGL(km, dim3(sl.wide ? wide_blocks : main_blocks), dim3(gact::kBlockThreads), 0, sl.stream, kp,
+                           e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file, sl.overlaps.p,
+                           queues(sl), sl.d_ws);
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -340,12 +349,14 @@ template <int C> int occupancy_blocks(int *out)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
     int m = std::min(a, b);
-    for (int v = 0; v < 4; v++) {
+    for (int v = 0; v < 6; v++) {
         int c = m;
         auto k = v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
                : v == 1 ? gact::extend_p16_kernel<gact::UniformLayout<C>, false>
                : v == 2 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
-                        : gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>;
+               : v == 3 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>
+               : v == 4 ? gact::extend_p16_kernel<gact::WideLayout, true>
+                        : gact::extend_p16_kernel<gact::WideLayout, false>;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k, gact::kBlockThreads, 0));
         m = std::min(m, c);
     }
@@ -458,6 +469,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
                getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
+    e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
     e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;
     static_assert(gact::GeometrySplit<7, 13>::kWsWords <= gact::Geometry<20>::kWsWords, "workspace too small");
     e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);
@@ -769,7 +781,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
     st->main_ms = st->total_ms;
-    st->packed16 = sl.two_phase ? (e->split ? 2 : 1) : 0;
+    st->packed16 = sl.two_phase ? (sl.wide ? 3 : e->split ? 2 : 1) : 0;
     st->seed_packed16 = (sl.two_phase && e->seed16) ? 1 : 0;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));

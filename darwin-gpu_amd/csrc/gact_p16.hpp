@@ -143,11 +143,15 @@ __host__ inline bool p16_argmax_ok(int tile, int match) { return (long long)matc
 
 struct P16Best { int best[2], bi[2], bj[2]; };
 
-template <int C> struct GeometryP16 {
-    static constexpr int kTileMax = C * kGroup;
-    static constexpr int kMaxSteps = kTileMax + kGroup;
+// LANES lanes per tile pair: 16 (one DPP row), or 32 for the latency-bound regime (two rows, half the columns
+// per lane, half the instructions per step; see WideLayout)
+template <int C, int LANES = kGroup> struct GeometryP16 {
+    static constexpr int kTileMax = C * LANES;
+    static constexpr int kMaxSteps = kTileMax + LANES;
+    static constexpr int kQuads = (C + 3) / 4;                     // 16-byte column quads stored per lane
+    static constexpr int kWsWords = ((kMaxSteps + 7) / 8 + 1) * kQuads * 4 * LANES;
     // ref stream: one 16-bit entry per step-row, byte 0 = tile A's base, byte 1 = tile B's
-    static constexpr int kRefEntries = kGroup + kMaxSteps + kTileMax + kGroup;
+    static constexpr int kRefEntries = LANES + kMaxSteps + kTileMax + LANES;
     static constexpr int kRefBytes = kRefEntries * 2;
     static constexpr int kQueryBytes = kTileMax * kSlots;
     static constexpr int kGroupLds = (kRefBytes + kQueryBytes + 15) & ~15;
@@ -169,7 +173,7 @@ template <int C> struct GeometryP16 {
 // (one right shift of (match - mismatch) << 24 by the row's stream byte, 24 - 8 r; a pad row's byte is 31 and
 // shifts everything out), and a slot's v_perm_b32 -- its selector bytes are the two query codes, fixed per
 // tile -- picks both tiles' values at once; Mx = (H + mismatch) + that: 2 ops per cell pair.
-template <int C, bool AMAX = false, bool RAW = true>
+template <int C, bool AMAX = false, bool RAW = true, int LANES = kGroup>
 __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                                             const uint16_t *__restrict__ ref16,
                                             const uint32_t (&qb)[C],
@@ -183,14 +187,17 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
     //   accO  2 bits/row  op code  0 ZERO, 1 MATCH, 2 INSERT, 3 DELETE   = nz * (1 + na * (1 + nb))
     //   accF  2 bits/row  {ins_open < ins_extend, del_open < del_extend}  (the complements of align.cpp:170-171)
     // built arithmetically: a comparison is the sign bit of a packed difference, or min(difference, 1)
-    uint32_t accO[C], accF[C];
+    constexpr int QD = (C + 3) / 4;         // column quads per lane (the last one may be partly unused)
+    static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
+    uint32_t accO[QD * 4], accF[QD * 4];
 #pragma unroll
     for (int c = 0; c < C; c++) {
         Hm[c] = hbias;                      // H[0][j] = 0
         Mo[c] = kc.open;                    // M[0][j] + gap_open
         Iup[c] = kc.ninf;                   // I[0][j] = -INF
-        accO[c] = 0; accF[c] = 0;
     }
+#pragma unroll
+    for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
     uint32_t Mo_last = kc.open, D_last = kc.ninf, Hm_last = hbias;
     uint32_t Hm_left_prev = hbias;
     uint32_t Ml0 = kc.open, Dl0 = kc.ninf, Hl = hbias;          // what lane gl-1 shows
@@ -232,9 +239,15 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         }
 
         // lane 0 of each destination keeps what it held: the j = 0 border it was initialised with
-        Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)Ml0);
-        Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)Dl0);
-        Hl = (uint32_t)dpp_row_shr1((int)Hm_last, (int)Hl);
+        if (LANES == 32) {
+            Ml0 = (uint32_t)dpp_shr1_32((int)Mo_last, (int)Ml0);
+            Dl0 = (uint32_t)dpp_shr1_32((int)D_last, (int)Dl0);
+            Hl = (uint32_t)dpp_shr1_32((int)Hm_last, (int)Hl);
+        } else {
+            Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)Ml0);
+            Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)Dl0);
+            Hl = (uint32_t)dpp_row_shr1((int)Hm_last, (int)Hl);
+        }
         uint32_t Hd = Hm_left_prev;
         Hm_left_prev = Hl;
 
@@ -313,14 +326,14 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         step(t, std::true_type{});
         if ((k & 7) == 7) {
 #pragma unroll
-            for (int q = 0; q < C / 4; q++) {
-                qA[q * kGroup] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
+            for (int q = 0; q < QD; q++) {
+                qA[q * LANES] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
                                             wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
-                qB[q * kGroup] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
-                                            wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
+                qB[q * LANES] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
+                                           wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
             }
-            qA += (C / 4) * kGroup;
-            qB += (C / 4) * kGroup;
+            qA += QD * LANES;
+            qB += QD * LANES;
             if (AMAX) fold(k - 7);
         }
     }
@@ -354,10 +367,10 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         const int sh = 2 * (8 - (k & 7));
         auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
 #pragma unroll
-        for (int q = 0; q < C / 4; q++) {
-            qA[q * kGroup] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+        for (int q = 0; q < QD; q++) {
+            qA[q * LANES] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
                                         just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
-            qB[q * kGroup] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+            qB[q * LANES] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
                                         just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
         }
     }
@@ -376,16 +389,16 @@ struct PairTile {
     int comp[kSlots];
 };
 
-template <int C, bool RAW>
+template <int C, bool RAW, int LANES = kGroup>
 __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc,
                                           const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8,
                                           uint32_t (&qb)[C])
 {
-    using G = GeometryP16<C>;
+    using G = GeometryP16<C, LANES>;
     // pad the whole stream: rows in front of row 1 (skew + start delay) and behind row R
     GACT_STAMP(l_a);
     uint32_t *ref32 = reinterpret_cast<uint32_t *>(ref8);
-    for (int k = gl; k < G::kRefBytes / 4; k += kGroup) ref32[k] = RAW ? 0xffffffffu : kLutPadRow * 0x01010101u;
+    for (int k = gl; k < G::kRefBytes / 4; k += LANES) ref32[k] = RAW ? 0xffffffffu : kLutPadRow * 0x01010101u;
     wave_sync();
     GACT_STAMP(l_b);
     // all loads first (addresses clamped into the slice, never predicated, so they are all in
@@ -414,7 +427,7 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 #pragma unroll
     for (int h = 0; h < kSlots; h++) {
         const int R = pt.R[h], Q = pt.Q[h];
-        uint8_t *rrow = ref8 + (kGroup + pt.shift[h]) * 2 + h;
+        uint8_t *rrow = ref8 + (LANES + pt.shift[h]) * 2 + h;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const int d = gl * C + c;
@@ -443,27 +456,34 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 // ---------------------------------------------------------------------------
 // Column layout policy of the packed pass: how a tile's columns map to (lane, slot),
 // which pass / loader go with it, and where the walker finds a cell's pointer word.
-template <int C> struct UniformLayout {
-    using G = GeometryP16<C>;
+template <int C, int LANES = kGroup> struct UniformLayout {
+    using G = GeometryP16<C, LANES>;
+    static constexpr int kLanes = LANES;                          // lanes per tile pair
     static constexpr int kSlotsPerLane = C;
-    static constexpr int kWalkCols = C, kWalkQuads = C / 4;       // columns / stored quads per lane for the walker
-    static constexpr int kRow0 = kGroup;                          // ref stream entry of (delay 0, row 1)
-    static constexpr int kBlocksPerCu = C <= 20 ? 3 : 1;          // register budget: 32 columns per lane need a whole SIMD's file
+    static constexpr int kWalkCols = C, kWalkQuads = G::kQuads;   // columns / stored quads per lane for the walker
+    static constexpr int kRow0 = LANES;                           // ref stream entry of (delay 0, row 1)
+    // register budget: 32 columns per lane need a whole SIMD's file
+    static constexpr int kBlocksPerCu = C <= 20 ? 3 : 1;
     __device__ static int last_step(int R, int Q) { return gact::last_step<C>(R, Q); }
     __device__ static int first_pointer_step(int R, int Q, int early) { return gact::first_pointer_step<C>(R, Q, early, false); }
     template <bool RAW>
     __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr,
                                 const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C])
-    { load_pair<C, RAW>(rs, qf, qr, pt, gl, ref8, q8, qb); }
+    { load_pair<C, RAW, LANES>(rs, qf, qr, pt, gl, ref8, q8, qb); }
     template <bool RAW>
     __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C], int T_end,
                                 int tB, uint32_t *wsA, uint32_t *wsB)
-    { dp_pass_p16<C, false, RAW>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    { dp_pass_p16<C, false, RAW, LANES>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
     // start cell (R, Q) of the traceback: lane, column in lane, stored step (tB_tile = tile's own first stored step)
     __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
     { l = (Q - 1) / C; c = (Q - 1) - l * C; k = R + l - tB_tile; }
     __device__ static int tile_tB(int tB, int shift) { return tB - shift; }
 };
+
+// The latency-bound regime (fewer chains than tile slots: the launch lasts as long as its longest chain): a tile
+// pair on 32 lanes with 10 columns each -- half the instructions per step, so a chain advances about twice as
+// fast, at 2 % more instructions per cell (both regions of a lane pay for pointers) and half as many tiles per wave.
+using WideLayout = UniformLayout<10, 32>;
 
 // ---------------------------------------------------------------------------
 // Persistent main kernel: every group carries two candidates (slot A / slot B).
@@ -475,18 +495,31 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     uint32_t *__restrict__ ws_all)
 {
     using G = typename L::G;
-    constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
+    constexpr int LANES = L::kLanes;                       // lanes per tile pair: 16, or 32 in the wide layout
+    constexpr int kGroupsOfWave = 64 / LANES;
+    constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsOfWave;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
     __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
 
-    const WaveCtx w = wave_ctx();
-    const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
+    WaveCtx w;
+    {
+        const int lane = threadIdx.x & 63;
+        const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+        w.gl = lane & (LANES - 1);
+        w.g = lane / LANES;
+        w.slot = wave * kGroupsOfWave + w.g;
+        w.n_slots = ((gridDim.x * blockDim.x) >> 6) * kGroupsOfWave;
+    }
+    const int group_in_block = (threadIdx.x >> 6) * kGroupsOfWave + w.g;
     uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
     uint8_t *q8 = ref8 + G::kRefBytes;
     const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (L::kRow0 - 1 - w.gl);
-    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
-    uint32_t *wsB = wsA + kp.ws_words;
+    // a wave owns 8 tile workspaces of kp.ws_words; with 32 lanes per pair it has 4 tiles, each of them two
+    constexpr int kWsPerTile = LANES / kGroup;
+    static_assert(G::kWsWords <= kWsPerTile * Geometry<20>::kWsWords || L::kSlotsPerLane > 20, "workspace stride");
+    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words * kWsPerTile;
+    uint32_t *wsB = wsA + (size_t)kp.ws_words * kWsPerTile;
 
     ChainState *st = chain_lds[group_in_block];
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
@@ -520,7 +553,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                     while (my_bucket < kBuckets) {
                         int idx = 0;
                         if (w.gl == 0) idx = atomicAdd(&cq.bucket_pop[my_bucket], 1);
-                        idx = __shfl(idx, 0, kGroup);
+                        idx = __shfl(idx, 0, LANES);
                         if (idx < cq.bucket_count[my_bucket]) {
                             cand = cq.live[(size_t)my_bucket * cq.live_stride + idx];
                             break;
@@ -554,10 +587,10 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
             continue;
         }
         // common end / common pointer start over the wave's 8 tiles (align_starts)
-        const int T_end = wave_max4(imax(have[0] ? Tend_h[0] : 0, have[1] ? Tend_h[1] : 0));
+        const int T_end = wave_max_groups<LANES>(imax(have[0] ? Tend_h[0] : 0, have[1] ? Tend_h[1] : 0));
         const int reach0 = have[0] ? tB_h[0] + (T_end - Tend_h[0]) : 0x7fffffff;
         const int reach1 = have[1] ? tB_h[1] + (T_end - Tend_h[1]) : 0x7fffffff;
-        const int tB = wave_min4(imin(reach0, reach1));
+        const int tB = wave_min_groups<LANES>(imin(reach0, reach1));
         pt.shift[0] = have[0] ? imax(0, tB - tB_h[0]) : 0;
         pt.shift[1] = have[1] ? imax(0, tB - tB_h[1]) : 0;
 
@@ -572,7 +605,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         // waves' DP instructions: run it at raised issue priority
         // ... and among the DP passes, the waves that carry the longest chains go first: when there are
         // fewer chains than tile slots the launch lasts as long as its longest chain
-        const int wave_longest = wave_max4(longest);
+        const int wave_longest = wave_max_groups<LANES>(longest);
         const int ref_longest = __builtin_amdgcn_readfirstlane(longest_running(cq, wave_longest, (threadIdx.x & 63) == 0));
         // ranking mode (prio_bases[0] == 0): prio_bases[1] = thresholds in sixteenths of the longest, hi << 8 | mid
         const bool rank_hi = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] >> 8) * ref_longest
@@ -605,7 +638,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 const uint8_t *qrow = q8 + h * G::kTileMax;
                 int l0, c0, k0;
                 L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
-                walk_chain<L::kWalkCols, 1, L::kWalkQuads>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
+                walk_chain<L::kWalkCols, 1, L::kWalkQuads, LANES>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
                                                            query_steps, nst);
             }
@@ -618,7 +651,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 ChainState s = st[h];
                 s.n_tiles++;
                 s.cells += (int64_t)pt.R[h] * pt.Q[h];
-                chain_advance(s, false, wk, ref_steps, query_steps, nst, h);
+                chain_advance<LANES>(s, false, wk, ref_steps, query_steps, nst, h);
                 wave_sync();
                 if (w.gl == 0) st[h] = s;
             }

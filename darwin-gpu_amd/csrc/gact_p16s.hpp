@@ -252,6 +252,7 @@ template <int C1, int C2> struct SplitLayout {
     using G = GeometrySplit<C1, C2>;
     static constexpr int kSlotsPerLane = C1 + C2;
     static constexpr int kWalkCols = C2, kWalkQuads = G::kQuads;
+    static constexpr int kLanes = kGroup;
     static constexpr int kRow0 = G::kRow0;
     static constexpr int kBlocksPerCu = 3;
     __device__ static int last_step(int R, int Q) { return split_last_step<C2>(R, Q); }

@@ -316,7 +316,7 @@ class Engine:
         st = RunStats()
         self._check(self.L.gact_hip_last_run_stats(self.h, slot, C.byref(st)))
         return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
-                "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split")[st.packed16],
+                "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split", "packed16-wide")[st.packed16],
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells}
 

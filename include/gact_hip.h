@@ -248,7 +248,8 @@ int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms);
 typedef struct {
     float total_ms, seed_ms, main_ms;   /* HIP events on the slot's stream */
     int32_t packed16;                   /* 0: one int32 launch; 1: seed + packed-int16 main launch, uniform
-                                           column layout; 2: the same, split (two-region) layout */
+                                           column layout; 2: the same, split (two-region) layout; 3: wide layout
+                                           (32 lanes per tile pair, chosen when there are few chains) */
     int32_t handed_off;                 /* candidates the main launch continued */
     int32_t seed_packed16;              /* 1: the seed launch ran the packed-int16 arg-max kernel, 0: the int32 one */
     int32_t reserved;

@@ -38,13 +38,19 @@ def _run(rs, cf, cr, oracle, scoring=(1, -1, -1, -1), tile=320, overlap=120, thr
     return total
 
 
-@pytest.fixture(params=["packed16", "packed16-uniform", "int32-seed", "int32"], autouse=True)
+@pytest.fixture(params=["packed16", "packed16-uniform", "packed16-wide", "int32-seed", "int32"], autouse=True)
 def kernel_family(request, monkeypatch):
-    """every chain test runs four times: packed seed + packed main launch in its split layout (default where
-    the geometry allows it), the same in the uniform layout, the int32 seed launch in front of the packed main
-    launch, and the int32 kernel alone"""
-    for var in ("GACT_HIP_FORCE_INT32", "GACT_HIP_FORCE_UNIFORM", "GACT_HIP_FORCE_INT32_SEED"):
+    """every chain test runs five times: packed seed + packed main launch in its split layout (what many chains
+    get where the geometry allows it), the same in the uniform layout, the same in the wide layout (32 lanes per
+    tile pair: what few chains get), the int32 seed launch in front of the packed main launch, and the int32
+    kernel alone"""
+    for var in ("GACT_HIP_FORCE_INT32", "GACT_HIP_FORCE_UNIFORM", "GACT_HIP_FORCE_INT32_SEED", "GACT_HIP_FORCE_WIDE",
+                "GACT_HIP_NO_WIDE"):
         monkeypatch.delenv(var, raising=False)
+    if request.param != "packed16-wide":
+        monkeypatch.setenv("GACT_HIP_NO_WIDE", "1")          # the tests' candidate lists are short
+    else:
+        monkeypatch.setenv("GACT_HIP_FORCE_WIDE", "1")
     if request.param == "int32":
         monkeypatch.setenv("GACT_HIP_FORCE_INT32", "1")
     elif request.param == "packed16-uniform":
@@ -64,7 +70,8 @@ def test_kernel_family_is_the_one_asked_for(kernel_family):
     eng.extend(cf)
     st = eng.last_run_stats()
     assert st["layout"] == {"packed16": "packed16-split", "packed16-uniform": "packed16-uniform",
-                            "int32-seed": "packed16-split", "int32": "int32"}[kernel_family]
+                            "packed16-wide": "packed16-wide", "int32-seed": "packed16-split",
+                            "int32": "int32"}[kernel_family]
     assert st["seed_layout"] == ("packed16" if kernel_family.startswith("packed16") else "int32")
     if st["packed16"]:
         assert 0 < st["handed_off"] <= len(cf) and st["seed_cells"] > 0

@@ -100,7 +100,8 @@ def test_dsoft_device_equals_reference(reflib, seed_size):
 
 @pytest.mark.parametrize("cfg", [dict(), dict(seed_size=12, window_size=5, threshold=25, bin_size=128),
                                  dict(seed_size=13, window_size=1, num_seeds=100),
-                                 dict(seed_size=10, window_size=9, seed_occurence_multiple=4, bin_size=48)])
+                                 dict(seed_size=10, window_size=9, seed_occurence_multiple=4, bin_size=48),
+                                 dict(seed_size=15, window_size=6)])          # the largest table: 4 GiB
 def test_dsoft_device_equals_host_restatement(tmp_path, cfg):
     """default parameters (k = 14: the 1 GiB direct table) and odd ones; reads with N runs, reads shorter than a
     window, homopolymer stretches (long runs of one window minimum)"""

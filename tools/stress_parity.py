@@ -1,0 +1,69 @@
+"""Randomised parity sweep: random tile geometry, thresholds, scorings, read sets with and without N, candidate
+lists with false and edge hits -- every record field against the oracle, in whichever kernels the engine picks
+plus the forced variants.  python tools/stress_parity.py [n_configs] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "darwin-gpu_amd"), os.path.join(ROOT, "oracle")]
+import numpy as np
+import oracle_py
+from gact_amd import engine, synth
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+orc = oracle_py.Oracle()
+FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
+MODES = [{}, {"GACT_HIP_FORCE_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_UNIFORM": "1"},
+         {"GACT_HIP_FORCE_INT32_SEED": "1"}, {"GACT_HIP_FORCE_INT32": "1"}]
+ALL = sorted({k for m in MODES for k in m})
+t0 = time.time()
+total = 0
+layouts = {}
+for it in range(n_cfg):
+    tile = int(rng.choice([64, 96, 128, 200, 256, 320, 320, 320, 384, 512]))
+    overlap = int(rng.integers(0, max(1, tile - 16)))
+    thr = int(rng.integers(1, 70))
+    match = int(rng.integers(1, 7))
+    scoring = (match, -int(rng.integers(0, 8)), -int(rng.integers(0, 12)), -int(rng.integers(0, 6)))
+    n_frac = float(rng.choice([0.0, 0.0, 0.004]))
+    rs = synth.simulate_reads(int(rng.integers(6000, 20000)), n_reads=int(rng.integers(6, 16)), seed=int(rng.integers(1 << 30)),
+                              mean_len=int(rng.integers(1500, 5000)), sd_len=900, min_len=200, max_len=9000, n_frac=n_frac)
+    cf, cr = synth.synth_candidates(rs, seed=int(rng.integers(1 << 30)), min_overlap=150,
+                                    false_frac=float(rng.choice([0.0, 0.3])))
+    cat, offs = rs.concat()
+    rcat, roffs = rs.concat(rc=True)
+    want = {}
+    for comp, cands, qcat, qoffs in ((False, cf, cat, offs), (True, cr, rcat, roffs)):
+        if len(cands):
+            want[comp], _ = orc.gact_many(cat, offs, qcat, qoffs, cands, complement=comp, same_file=True, tile_size=tile,
+                                          tile_overlap=overlap, threshold=thr, scoring=scoring, n_threads=16)
+    for mode in MODES:
+        for k in ALL:
+            os.environ.pop(k, None)
+        os.environ.update(mode)
+        eng = engine.Engine(tile_size=tile, tile_overlap=overlap, scoring=scoring, threshold=thr)
+        eng.upload(engine.SET_REF, cat, offs)
+        eng.upload(engine.SET_QUERY, cat, offs)
+        eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+        for comp, cands in ((False, cf), (True, cr)):
+            if not len(cands):
+                continue
+            got = eng.extend(cands, complement=comp, same_file=True)
+            st = eng.last_run_stats()
+            key = st["layout"] + "/" + st["seed_layout"]
+            layouts[key] = layouts.get(key, 0) + 1
+            for f in FIELDS:
+                if not np.array_equal(got[f], want[comp][f]):
+                    bad = int(np.flatnonzero(got[f] != want[comp][f])[0])
+                    print("MISMATCH config %d tile %d overlap %d thr %d scoring %s n_frac %g mode %s field %s cand %d"
+                          % (it, tile, overlap, thr, scoring, n_frac, mode, f, bad))
+                    print(" hip", got[bad], "\n ora", want[comp][bad])
+                    sys.exit(1)
+            total += len(cands)
+        eng.close()
+    if it % 10 == 9:
+        print("config %d/%d ok, %d candidate runs so far, %.0f s" % (it + 1, n_cfg, total, time.time() - t0), flush=True)
+print("stress parity: %d configurations x %d kernel selections, %d candidate runs, all BIT-EXACT; launches by kernels: %s"
+      % (n_cfg, len(MODES), total, layouts))

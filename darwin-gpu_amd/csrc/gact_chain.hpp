@@ -216,6 +216,11 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
+        } else if (FMT == 2) {
+            const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
+            const uint32_t op = v & 3u;                          // align.h:23 numbering Z0 D1 I2 M3
+            code = op ? 4u - op : 0u;
+            flags = (~v >> 16) & 3u;
         } else {
             const uint32_t nib = w >> ((~(uint32_t)k & 7u) * 4u);
             const uint32_t op = nib & 3u;                        // align.h:23 numbering Z0 D1 I2 M3

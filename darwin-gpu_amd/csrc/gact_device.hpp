@@ -487,6 +487,8 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
 // FMT 0: the int32 kernels' word, 8 rows x 4 bits {ins_open>=ins_extend, del_open>=del_extend, op}, first row on top.
 // FMT 1: the packed kernel's word, low half 8 rows x 2 bits op code (0 ZERO 1 MATCH 2 INSERT 3 DELETE),
 //        high half 8 rows x 2 bits {ins_open<ins_extend, del_open<del_extend}.
+// FMT 2: the tagged pass's word, low half 8 rows x 2 bits op in align.h:23 numbering (Z0 D1 I2 M3), high half
+//        8 rows x 2 bits {ins_open>=ins_extend, del_open>=del_extend}.
 
 // ---------------------------------------------------------------------------
 // Loads one group's tile into LDS + registers.  DP index d (0-based) of a

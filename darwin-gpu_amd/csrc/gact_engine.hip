@@ -162,6 +162,7 @@ struct gact_hip_engine {
     int C = 20;                 // columns per lane
     bool p16 = false;           // scoring fits the packed-int16 main kernel
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
+    bool tagged = false;        // ... with the tagged pointer scheme in its pointer phase
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
@@ -330,6 +331,8 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         sl.wide = C == 20 && e->wide >= 0 && (e->wide > 0 || n <= narrow_slots);
         auto km = sl.wide  ? (raw ? gact::extend_p16_kernel<gact::WideLayout, true>
                                   : gact::extend_p16_kernel<gact::WideLayout, false>)
+                : e->tagged ? (raw ? gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
+                                   : gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>)
                 : e->split ? (raw ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
                                   : gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>)
                            : (raw ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
@@ -349,14 +352,16 @@ template <int C> int occupancy_blocks(int *out)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
     int m = std::min(a, b);
-    for (int v = 0; v < 6; v++) {
+    for (int v = 0; v < 8; v++) {
         int c = m;
         auto k = v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
                : v == 1 ? gact::extend_p16_kernel<gact::UniformLayout<C>, false>
                : v == 2 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
                : v == 3 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>
                : v == 4 ? gact::extend_p16_kernel<gact::WideLayout, true>
-                        : gact::extend_p16_kernel<gact::WideLayout, false>;
+               : v == 5 ? gact::extend_p16_kernel<gact::WideLayout, false>
+               : v == 6 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
+                        : gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k, gact::kBlockThreads, 0));
         m = std::min(m, c);
     }
@@ -467,6 +472,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
              getenv("GACT_HIP_FORCE_INT32") == nullptr;
     e->split = e->p16 && e->C == 20 && e->kp.early <= gact::GeometrySplit<7, 13>::W2 &&
                getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
+    e->tagged = e->split && gact::p16_tagged_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
+                getenv("GACT_HIP_NO_TAGGED") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
@@ -476,6 +483,12 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->kc.open = gact::pk2(p->gap_open); e->kc.ext = gact::pk2(p->gap_extend);
     e->kc.ninf = gact::pk2(gact::kNegInf16); e->kc.one = gact::pk2(1);
     e->kc.mism = gact::pk2(p->mismatch); e->kc.dsub = (uint32_t)(p->match - p->mismatch) << 24;
+    e->kc.c3 = gact::pk2(3); e->kc.nmask = ~e->kc.c3; e->kc.tag1 = gact::pk2(1); e->kc.tag2 = gact::pk2(2);
+    e->kc.match4 = gact::pk2(4 * p->match); e->kc.mism4 = gact::pk2(4 * p->mismatch);
+    e->kc.nd4 = gact::pk2(4 * (p->mismatch - p->match));
+    e->kc.open4m2 = gact::pk2(4 * p->gap_open - 2); e->kc.ext4m2 = gact::pk2(4 * p->gap_extend - 2);
+    e->kc.ext4m1 = gact::pk2(4 * p->gap_extend - 1);
+    e->kc.dsub4 = (uint32_t)(4 * (p->match - p->mismatch)) << 24; e->kc.floor4 = gact::pk2(-6000);
 
     rc = (e->C == 20) ? occupancy_blocks<20>(&e->blocks_per_cu) : occupancy_blocks<32>(&e->blocks_per_cu);
     if (rc) { delete e; return rc; }

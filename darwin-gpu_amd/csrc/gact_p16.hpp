@@ -41,6 +41,16 @@ struct P16Consts {
     uint32_t match, nd /* mismatch - match */, open, ext, ninf, one;
     uint32_t mism;      // mismatch in both half-words
     uint32_t dsub;      // (match - mismatch) << 24 (LUT form of the substitution score)
+    // tagged form (dp_pass_p16s, TAG): scores times four, the two low bits of every value say where it came from
+    uint32_t c3;        // 3 in both half-words
+    uint32_t nmask;     // ~c3
+    uint32_t tag1, tag2;
+    uint32_t match4, mism4, nd4;          // 4 * (...)
+    uint32_t open4m2;   // 4 * gap_open - 2: takes an M tagged 3 to M + gap_open tagged 1
+    uint32_t ext4m2;    // 4 * gap_extend - 2: I tagged 2 -> ins_extend tagged 0
+    uint32_t ext4m1;    // 4 * gap_extend - 1: D tagged 1 -> del_extend tagged 0
+    uint32_t dsub4;     // 4 * (match - mismatch) << 24
+    uint32_t floor4;    // -6000: what is still -INF when the scores are scaled
 };
 
 __host__ __device__ inline uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -136,6 +146,13 @@ __device__ __forceinline__ uint32_t pk_mad_m1(uint32_t a, uint32_t b)           
     return r;
 }
 
+// tagged pointer scheme (split layout, pointer phase): 4 * score + 3 must fit, so must 4 * (match - mismatch) a byte
+__host__ inline bool p16_tagged_ok(int tile, int match, int mismatch, int open, int ext)
+{
+    return (long long)match * (tile + 2) <= 7900 && match - mismatch <= 63 && mismatch >= -1000 && open >= -1000 &&
+           ext >= -1000;
+}
+
 // arg-max of the packed pass (first tiles): the key H*8 + (step & 7) must stay under 2^14, so that a
 // row outside the tile can be keyed negative by a -2^14 bias
 constexpr int kKeyBias = -16384;
@@ -145,6 +162,31 @@ struct P16Best { int best[2], bi[2], bj[2]; };
 
 // LANES lanes per tile pair: 16 (one DPP row), or 32 for the latency-bound regime (two rows, half the columns
 // per lane, half the instructions per step; see WideLayout)
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t vmask, uint32_t s_or)      // (a & vmask) | s_or
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(vmask), "s"(s_or));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_lshr2(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_lshrrev_b16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_mad4(uint32_t a, uint32_t s_c)      // a * 4 + c (wrapping halves)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(s_c));
+    return r;
+}
+
 template <int C, int LANES = kGroup> struct GeometryP16 {
     static constexpr int kTileMax = C * LANES;
     static constexpr int kMaxSteps = kTileMax + LANES;
@@ -460,7 +502,7 @@ template <int C, int LANES = kGroup> struct UniformLayout {
     using G = GeometryP16<C, LANES>;
     static constexpr int kLanes = LANES;                          // lanes per tile pair
     static constexpr int kSlotsPerLane = C;
-    static constexpr int kWalkCols = C, kWalkQuads = G::kQuads;   // columns / stored quads per lane for the walker
+    static constexpr int kWalkCols = C, kWalkQuads = G::kQuads, kWalkFmt = 1;   // for the walker
     static constexpr int kRow0 = LANES;                           // ref stream entry of (delay 0, row 1)
     // register budget: 32 columns per lane need a whole SIMD's file
     static constexpr int kBlocksPerCu = C <= 20 ? 3 : 1;
@@ -638,7 +680,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 const uint8_t *qrow = q8 + h * G::kTileMax;
                 int l0, c0, k0;
                 L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
-                walk_chain<L::kWalkCols, 1, L::kWalkQuads, LANES>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
+                walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, LANES>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
                                                            query_steps, nst);
             }

@@ -65,7 +65,17 @@ template <int C2> __device__ __forceinline__ int split_first_pointer_step(int R,
 
 // ---------------------------------------------------------------------------
 // ref16[t] / ref16[t - 16] hold the bases of region 1's / region 2's row at step t.
-template <int C1, int C2, bool RAW = true>
+//
+// TAG: in the pointer phase region 2 runs on scores times four whose two low bits say where a value came from, so
+// that the `max` operations the recurrence needs anyway also produce the pointer bits:
+//   ins: max(M+open tagged 1, ins_extend tagged 0) -> bit 0 of the result = (ins_open >= ins_extend), ties included
+//   del: likewise
+//   H:   max(M tagged 3, I tagged 2, D tagged 1) -> the low bits are the op in align.h:23 numbering (M3 I2 D1), with
+//        the reference's priority on ties; M is kept as max(.., 3), so H == 0 shows as H' <= 3 -> ZERO
+// Re-tagging costs three ops per cell pair, the explicit comparisons it replaces cost six more: 22 instead of 25.
+// Region 1 and the score-only phase stay on plain scores; region 1's last column is converted as it crosses into
+// region 2 (three ops per step), region 2's state once when the pointer phase begins.  Pointer words: FMT 2.
+template <int C1, int C2, bool RAW = true, bool TAG = false>
 __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
                                              const uint16_t *__restrict__ ref16,
                                              const uint32_t (&qb)[C1 + C2],
@@ -158,16 +168,105 @@ __device__ __forceinline__ void dp_pass_p16s(const P16Consts &kc, const int gl,
         set_rows(w1, w2);
     };
 
+    // ---- TAG: the pointer-phase step.  Region-2 registers hold: Hm = 4(H+bias)+3, Mo = 4(M+open)+1, Iup = the
+    //      next row's ins_extend 4(I+ext) (tag 0); the lane-boundary values Mo2 / D2 / H2 tagged 1 / 1 / 3.
+    const uint32_t hbias4 = RAW ? kc.match4 : kc.mism4;
+    const uint32_t vmask = kc.nmask;                    // in a VGPR: v_and_or_b32 takes one scalar operand
+    auto lut4 = [&](uint32_t amount) { return kc.dsub4 >> (amount & 31u); };
+    auto step_tagged = [&](const int t) {
+        const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
+        Ml1 = (uint32_t)dpp_row_shr1((int)Mo1, (int)Ml1);
+        Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
+        Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Hl1);
+        // lane 15's region-1 column enters region 2: scaled and tagged like a region-2 column
+        const uint32_t Ml2 = (uint32_t)dpp_row_shr1((int)Mo2, dpp_row_ror1((int)pk_mad4(Mo1, kc.tag1)));
+        const uint32_t Dl2 = (uint32_t)dpp_row_shr1((int)D2, dpp_row_ror1((int)pk_mad4(D1, kc.tag1)));
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4(H1, kc.c3)));
+        uint32_t Hd = Hdiag1;
+        Hdiag1 = Hl1;
+
+        uint32_t M[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
+            if (c < C1) {                                                       // plain, as in step()
+                uint32_t Mx;
+                if (RAW) Mx = pk_mad_s(pk_min1(qb[c] ^ rb1), kc.nd, Hd);
+                else Mx = pk_add(Hd, __builtin_amdgcn_perm(rb1b, rb1, qb[c]));
+                Hd = Hm[c];
+                M[c] = pk_max0(Mx);
+                const uint32_t Ie = pk_add_s(Iup[c], kc.ext);
+                Iup[c] = pk_max(Mo[c], Ie);
+                Mo[c] = pk_add_s(M[c], kc.open);
+            } else {
+                uint32_t Mx;                                                    // 4(H[i-1][j-1] + sub) + 3
+                if (RAW) Mx = pk_mad_s(pk_min1(qb[c] ^ rb2), kc.nd4, Hd);
+                else Mx = pk_add(Hd, __builtin_amdgcn_perm(rb2b, rb2, qb[c]));
+                Hd = Hm[c];
+                M[c] = pk_max_s(Mx, kc.c3);                                     // 4M + 3, M >= 0       :145-147
+                Iup[c] = pk_max(Mo[c], Iup[c]);                                 // bit 0: ins_open >= ins_extend   :154,170
+                Mo[c] = pk_add_s(M[c], kc.open4m2);                             // 4(M + open) + 1
+            }
+        }
+        uint32_t Ml = Ml1, Dl = Dl1;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c == C1) {
+                Mo1 = Ml; D1 = Dl; H1 = Hm[C1 - 1];
+                Ml = Ml2; Dl = Dl2;
+            }
+            if (c < C1) {
+                const uint32_t De = pk_add_s(Dl, kc.ext);
+                const uint32_t D = pk_max(Ml, De);
+                const uint32_t H = pk_max(pk_max(M[c], Iup[c]), D);
+                Hm[c] = pk_add_s(H, hbias);
+                Ml = Mo[c];
+                Dl = D;
+            } else {
+                const uint32_t De = pk_add_s(Dl, kc.ext4m1);                    // 4 del_extend, tag 0   :152
+                const uint32_t Dp = pk_max(Ml, De);                             // bit 0: del_open >= del_extend   :156,171
+                const uint32_t Dt = and_or(Dp, vmask, kc.tag1);
+                const uint32_t It = and_or(Iup[c], vmask, kc.tag2);
+                const uint32_t Hp = pk_max(pk_max(M[c], It), Dt);               // :158-168
+                accF[c - C1] = pk_shl_add4(accF[c - C1], pk_shl_add2(Iup[c], Dp) & kc.c3);
+                const uint32_t op = pk_mul(Hp & kc.c3, pk_min1(pk_lshr2(Hp)));  // H == 0: ZERO
+                accO[c - C1] = pk_shl_add4(accO[c - C1], op);
+                Hm[c] = pk_add_s(Hp | kc.c3, hbias4);
+                Iup[c] = pk_add_s(It, kc.ext4m2);                               // the next row's ins_extend   :150
+                Ml = Mo[c];
+                Dl = Dt;
+            }
+        }
+        Mo2 = Ml; D2 = Dl; H2 = Hm[CT - 1];
+        if (RAW) { rb1 = unpack(w1); rb2 = unpack(w2); }
+        else { rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8); }
+    };
+    // plain -> tagged, once, when the pointer phase begins
+    auto enter_tagged = [&]() {
+#pragma unroll
+        for (int c = C1; c < CT; c++) {
+            Hm[c] = pk_mad4(Hm[c], kc.c3);
+            Mo[c] = pk_mad4(Mo[c], kc.tag1);
+            Iup[c] = pk_add_s(pk_mad4(pk_max_s(Iup[c], kc.floor4), kc.tag2), kc.ext4m2);
+        }
+        Mo2 = pk_mad4(Mo2, kc.tag1);
+        D2 = pk_mad4(pk_max_s(D2, kc.floor4), kc.tag1);
+        H2 = pk_mad4(H2, kc.c3);
+        Hdiag2 = pk_mad4(Hdiag2, kc.c3);
+        if (!RAW) { rb2 = rb2 << 2; rb2b = rb2b << 2; }     // the row already fetched: bonus times four
+    };
+
     auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
     auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
 
     int t = 1;
     for (; t < tB && t <= T_end; t++) step(t, std::false_type{});
+    if (TAG) enter_tagged();
     uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
     uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
     int k = 0;
     for (; t <= T_end; t++, k++) {
-        step(t, std::true_type{});
+        if (TAG) step_tagged(t); else step(t, std::true_type{});
         if ((k & 7) == 7) {
 #pragma unroll
             for (int q = 0; q < QD; q++) {
@@ -248,10 +347,10 @@ __device__ __forceinline__ void load_pair_split(const SeqSetDev &rs, const SeqSe
 
 // ---------------------------------------------------------------------------
 // Layout policy for extend_p16_kernel (gact_p16.hpp).  Requires early <= 16*C2 (window inside region 2).
-template <int C1, int C2> struct SplitLayout {
+template <int C1, int C2, bool TAG = false> struct SplitLayout {
     using G = GeometrySplit<C1, C2>;
     static constexpr int kSlotsPerLane = C1 + C2;
-    static constexpr int kWalkCols = C2, kWalkQuads = G::kQuads;
+    static constexpr int kWalkCols = C2, kWalkQuads = G::kQuads, kWalkFmt = TAG ? 2 : 1;
     static constexpr int kLanes = kGroup;
     static constexpr int kRow0 = G::kRow0;
     static constexpr int kBlocksPerCu = 3;
@@ -264,7 +363,7 @@ template <int C1, int C2> struct SplitLayout {
     template <bool RAW>
     __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
                                 int T_end, int tB, uint32_t *wsA, uint32_t *wsB)
-    { dp_pass_p16s<C1, C2, RAW>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    { dp_pass_p16s<C1, C2, RAW, TAG>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
     // the start cell (R, Q) is the last column of region 2: lane 15, slot C2-1
     __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
     { (void)Q; l = kGroup - 1; c = C2 - 1; k = R + (kGroup - 1) - tB_tile; }

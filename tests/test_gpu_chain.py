@@ -38,15 +38,19 @@ def _run(rs, cf, cr, oracle, scoring=(1, -1, -1, -1), tile=320, overlap=120, thr
     return total
 
 
-@pytest.fixture(params=["packed16", "packed16-uniform", "packed16-wide", "int32-seed", "int32"], autouse=True)
+@pytest.fixture(params=["packed16", "packed16-plain", "packed16-uniform", "packed16-wide", "int32-seed", "int32"],
+                autouse=True)
 def kernel_family(request, monkeypatch):
-    """every chain test runs five times: packed seed + packed main launch in its split layout (what many chains
-    get where the geometry allows it), the same in the uniform layout, the same in the wide layout (32 lanes per
+    """every chain test runs six times: packed seed + packed main launch in its split layout (what many chains
+    get where the geometry allows it; tagged pointer scheme where the scoring allows it), the same with explicit
+    pointer comparisons, the same in the uniform layout, the same in the wide layout (32 lanes per
     tile pair: what few chains get), the int32 seed launch in front of the packed main launch, and the int32
     kernel alone"""
     for var in ("GACT_HIP_FORCE_INT32", "GACT_HIP_FORCE_UNIFORM", "GACT_HIP_FORCE_INT32_SEED", "GACT_HIP_FORCE_WIDE",
-                "GACT_HIP_NO_WIDE"):
+                "GACT_HIP_NO_WIDE", "GACT_HIP_NO_TAGGED"):
         monkeypatch.delenv(var, raising=False)
+    if request.param == "packed16-plain":
+        monkeypatch.setenv("GACT_HIP_NO_TAGGED", "1")        # split layout with explicit pointer comparisons
     if request.param != "packed16-wide":
         monkeypatch.setenv("GACT_HIP_NO_WIDE", "1")          # the tests' candidate lists are short
     else:
@@ -69,7 +73,8 @@ def test_kernel_family_is_the_one_asked_for(kernel_family):
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
     eng.extend(cf)
     st = eng.last_run_stats()
-    assert st["layout"] == {"packed16": "packed16-split", "packed16-uniform": "packed16-uniform",
+    assert st["layout"] == {"packed16": "packed16-split", "packed16-plain": "packed16-split",
+                            "packed16-uniform": "packed16-uniform",
                             "packed16-wide": "packed16-wide", "int32-seed": "packed16-split",
                             "int32": "int32"}[kernel_family]
     assert st["seed_layout"] == ("packed16" if kernel_family.startswith("packed16") else "int32")

@@ -15,7 +15,8 @@ n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 orc = oracle_py.Oracle()
 FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
-MODES = [{}, {"GACT_HIP_FORCE_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_UNIFORM": "1"},
+MODES = [{}, {"GACT_HIP_FORCE_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_TAGGED": "1"},
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_UNIFORM": "1"},
          {"GACT_HIP_FORCE_INT32_SEED": "1"}, {"GACT_HIP_FORCE_INT32": "1"}]
 ALL = sorted({k for m in MODES for k in m})
 t0 = time.time()
@@ -24,6 +25,8 @@ layouts = {}
 for it in range(n_cfg):
     tile = int(rng.choice([64, 96, 128, 200, 256, 320, 320, 320, 384, 512]))
     overlap = int(rng.integers(0, max(1, tile - 16)))
+    if rng.random() < 0.4:                       # the reference's geometry class: split layout, tagged pointers
+        tile, overlap = 320, int(rng.integers(112, 300))
     thr = int(rng.integers(1, 70))
     match = int(rng.integers(1, 7))
     scoring = (match, -int(rng.integers(0, 8)), -int(rng.integers(0, 12)), -int(rng.integers(0, 6)))

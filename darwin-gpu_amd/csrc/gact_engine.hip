@@ -796,6 +796,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     st->main_ms = st->total_ms;
     st->packed16 = sl.two_phase ? (sl.wide ? 3 : e->split ? 2 : 1) : 0;
     st->seed_packed16 = (sl.two_phase && e->seed16) ? 1 : 0;
+    st->tagged_pointers = (sl.two_phase && !sl.wide && e->tagged) ? 1 : 0;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
         HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));

@@ -46,7 +46,7 @@ class DeviceInfo(C.Structure):
 class RunStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("seed_ms", C.c_float), ("main_ms", C.c_float),
                 ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_packed16", C.c_int32),
-                ("reserved", C.c_int32), ("seed_cells", C.c_int64)]
+                ("tagged_pointers", C.c_int32), ("seed_cells", C.c_int64)]
 
 
 class DsoftParams(C.Structure):
@@ -318,6 +318,7 @@ class Engine:
         return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
                 "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split", "packed16-wide")[st.packed16],
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
+                "tagged_pointers": bool(st.tagged_pointers),
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells}
 
     def measure_valu_rate(self):

@@ -184,8 +184,10 @@ def main():
         main_kernel = {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
                        "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>",
                        "packed16-wide": "extend_p16_kernel<WideLayout>"}[kernel_ms[-1]["layout"]]
-        if kernel_ms[-1]["tagged_pointers"]:
-            main_kernel = "extend_p16_kernel<SplitLayout<7,13,true>>"
+        if kernel_ms[-1]["tagged_pointers"]:           # pointer phase on tagged scores: the layouts' TAG variants
+            main_kernel = {"extend_p16_kernel<UniformLayout<20>>": "extend_p16_kernel<UniformLayout<20,16,true>>",
+                           "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
+                           "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutTagged>"}[main_kernel]
         measured_rate = eng.measure_valu_rate()
         peak_tops = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
         # HBM bytes of the main launch cannot be counted from inside this process: they come from the separate

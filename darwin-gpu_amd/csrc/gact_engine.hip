@@ -162,7 +162,7 @@ struct gact_hip_engine {
     int C = 20;                 // columns per lane
     bool p16 = false;           // scoring fits the packed-int16 main kernel
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
-    bool tagged = false;        // ... with the tagged pointer scheme in its pointer phase
+    bool tagged = false;        // the packed main launch runs its pointer phase on tagged scores (any layout)
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
@@ -329,14 +329,18 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
         const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
         sl.wide = C == 20 && e->wide >= 0 && (e->wide > 0 || n <= narrow_slots);
-        auto km = sl.wide  ? (raw ? gact::extend_p16_kernel<gact::WideLayout, true>
-                                  : gact::extend_p16_kernel<gact::WideLayout, false>)
-                : e->tagged ? (raw ? gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
-                                   : gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>)
-                : e->split ? (raw ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
-                                  : gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>)
-                           : (raw ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
-                                  : gact::extend_p16_kernel<gact::UniformLayout<C>, false>);
+        using gact::extend_p16_kernel;
+        const bool tg = e->tagged;
+        auto km = sl.wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
+                                : (raw ? extend_p16_kernel<gact::WideLayout, true> : extend_p16_kernel<gact::WideLayout, false>))
+                : e->split ? (tg ? (raw ? extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
+                                        : extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>)
+                                 : (raw ? extend_p16_kernel<gact::SplitLayout<7, 13>, true>
+                                        : extend_p16_kernel<gact::SplitLayout<7, 13>, false>))
+                           : (tg ? (raw ? extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, true>
+                                        : extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, false>)
+                                 : (raw ? extend_p16_kernel<gact::UniformLayout<C>, true>
+                                        : extend_p16_kernel<gact::UniformLayout<C>, false>));
         const int wide_blocks = std::max(1, std::min((n + 15) / 16, e->grid_blocks));      // 4 tiles per wave
         hipLaunchKernelGGL(km, dim3(sl.wide ? wide_blocks : main_blocks), dim3(gact::kBlockThreads), 0, sl.stream, kp,
                            e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file, sl.overlaps.p,
@@ -352,7 +356,7 @@ template <int C> int occupancy_blocks(int *out)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
     int m = std::min(a, b);
-    for (int v = 0; v < 8; v++) {
+    for (int v = 0; v < 12; v++) {
         int c = m;
         auto k = v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
                : v == 1 ? gact::extend_p16_kernel<gact::UniformLayout<C>, false>
@@ -361,7 +365,11 @@ template <int C> int occupancy_blocks(int *out)
                : v == 4 ? gact::extend_p16_kernel<gact::WideLayout, true>
                : v == 5 ? gact::extend_p16_kernel<gact::WideLayout, false>
                : v == 6 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
-                        : gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>;
+               : v == 7 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>
+               : v == 8 ? gact::extend_p16_kernel<gact::WideLayoutTagged, true>
+               : v == 9 ? gact::extend_p16_kernel<gact::WideLayoutTagged, false>
+               : v == 10 ? gact::extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, true>
+                         : gact::extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, false>;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k, gact::kBlockThreads, 0));
         m = std::min(m, c);
     }
@@ -472,7 +480,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
              getenv("GACT_HIP_FORCE_INT32") == nullptr;
     e->split = e->p16 && e->C == 20 && e->kp.early <= gact::GeometrySplit<7, 13>::W2 &&
                getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
-    e->tagged = e->split && gact::p16_tagged_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
+    e->tagged = e->p16 && gact::p16_tagged_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
                 getenv("GACT_HIP_NO_TAGGED") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
@@ -796,7 +804,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     st->main_ms = st->total_ms;
     st->packed16 = sl.two_phase ? (sl.wide ? 3 : e->split ? 2 : 1) : 0;
     st->seed_packed16 = (sl.two_phase && e->seed16) ? 1 : 0;
-    st->tagged_pointers = (sl.two_phase && !sl.wide && e->tagged) ? 1 : 0;
+    st->tagged_pointers = (sl.two_phase && e->tagged) ? 1 : 0;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
         HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));

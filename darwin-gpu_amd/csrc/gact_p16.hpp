@@ -215,7 +215,8 @@ template <int C, int LANES = kGroup> struct GeometryP16 {
 // (one right shift of (match - mismatch) << 24 by the row's stream byte, 24 - 8 r; a pad row's byte is 31 and
 // shifts everything out), and a slot's v_perm_b32 -- its selector bytes are the two query codes, fixed per
 // tile -- picks both tiles' values at once; Mx = (H + mismatch) + that: 2 ops per cell pair.
-template <int C, bool AMAX = false, bool RAW = true, int LANES = kGroup>
+// TAG: the pointer phase on tagged scores (see dp_pass_p16s); not for the arg-max pass, whose keys are built from H.
+template <int C, bool AMAX = false, bool RAW = true, int LANES = kGroup, bool TAG = false>
 __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
                                             const uint16_t *__restrict__ ref16,
                                             const uint32_t (&qb)[C],
@@ -231,6 +232,7 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
     // built arithmetically: a comparison is the sign bit of a packed difference, or min(difference, 1)
     constexpr int QD = (C + 3) / 4;         // column quads per lane (the last one may be partly unused)
     static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
+    static_assert(!(AMAX && TAG), "the arg-max pass keeps plain scores");
     uint32_t accO[QD * 4], accF[QD * 4];
 #pragma unroll
     for (int c = 0; c < C; c++) {
@@ -333,6 +335,68 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         set_row(w_next);
     };
 
+    // ---- TAG: the pointer-phase step on tagged scores (register contents as in dp_pass_p16s)
+    const uint32_t hbias4 = RAW ? kc.match4 : kc.mism4;
+    const uint32_t vmask = kc.nmask;
+    auto lut4 = [&](uint32_t amount) { return kc.dsub4 >> (amount & 31u); };
+    auto step_tagged = [&](const int t) {
+        const uint32_t w_next = ref16[t + 1];
+        if (LANES == 32) {
+            Ml0 = (uint32_t)dpp_shr1_32((int)Mo_last, (int)Ml0);
+            Dl0 = (uint32_t)dpp_shr1_32((int)D_last, (int)Dl0);
+            Hl = (uint32_t)dpp_shr1_32((int)Hm_last, (int)Hl);
+        } else {
+            Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)Ml0);
+            Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)Dl0);
+            Hl = (uint32_t)dpp_row_shr1((int)Hm_last, (int)Hl);
+        }
+        uint32_t Hd = Hm_left_prev;
+        Hm_left_prev = Hl;
+        uint32_t M[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            uint32_t Mx;                                                    // 4(H[i-1][j-1] + sub) + 3
+            if (RAW) Mx = pk_mad_s(pk_min1(qb[c] ^ rbp), kc.nd4, Hd);
+            else Mx = pk_add(Hd, __builtin_amdgcn_perm(lutB, lutA, qb[c]));
+            Hd = Hm[c];
+            M[c] = pk_max_s(Mx, kc.c3);                                     // 4M + 3, M >= 0
+            Iup[c] = pk_max(Mo[c], Iup[c]);                                 // bit 0: ins_open >= ins_extend
+            Mo[c] = pk_add_s(M[c], kc.open4m2);                             // 4(M + open) + 1
+        }
+        uint32_t Ml = Ml0, Dl = Dl0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t De = pk_add_s(Dl, kc.ext4m1);
+            const uint32_t Dp = pk_max(Ml, De);                             // bit 0: del_open >= del_extend
+            const uint32_t Dt = and_or(Dp, vmask, kc.tag1);
+            const uint32_t It = and_or(Iup[c], vmask, kc.tag2);
+            const uint32_t Hp = pk_max(pk_max(M[c], It), Dt);
+            accF[c] = pk_shl_add4(accF[c], pk_shl_add2(Iup[c], Dp) & kc.c3);
+            accO[c] = pk_shl_add4(accO[c], pk_mul(Hp & kc.c3, pk_min1(pk_lshr2(Hp))));       // H == 0: ZERO
+            Hm[c] = pk_add_s(Hp | kc.c3, hbias4);
+            Iup[c] = pk_add_s(It, kc.ext4m2);                               // the next row's ins_extend
+            Ml = Mo[c];
+            Dl = Dt;
+        }
+        Mo_last = Ml;
+        D_last = Dl;
+        Hm_last = Hm[C - 1];
+        if (RAW) rbp = unpack(w_next);
+        else { lutA = lut4(w_next & 0xffu); lutB = lut4(w_next >> 8); }
+    };
+    auto enter_tagged = [&]() {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            Hm[c] = pk_mad4(Hm[c], kc.c3);
+            Mo[c] = pk_mad4(Mo[c], kc.tag1);
+            Iup[c] = pk_add_s(pk_mad4(pk_max_s(Iup[c], kc.floor4), kc.tag2), kc.ext4m2);
+        }
+        Mo_last = pk_mad4(Mo_last, kc.tag1); Ml0 = pk_mad4(Ml0, kc.tag1);
+        D_last = pk_mad4(pk_max_s(D_last, kc.floor4), kc.tag1); Dl0 = pk_mad4(pk_max_s(Dl0, kc.floor4), kc.tag1);
+        Hm_last = pk_mad4(Hm_last, kc.c3); Hl = pk_mad4(Hl, kc.c3); Hm_left_prev = pk_mad4(Hm_left_prev, kc.c3);
+        if (!RAW) { lutA <<= 2; lutB <<= 2; }
+    };
+
     // tile A's word = {accF.lo, accO.lo}, tile B's = {accF.hi, accO.hi}: flags in the high half-word
     auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
     auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
@@ -361,11 +425,12 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
 
     int t = 1;
     for (; t < tB && t <= T_end; t++) step(t, std::false_type{});
+    if (TAG) enter_tagged();
     uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
     uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
     int k = 0;
     for (; t <= T_end; t++, k++) {
-        step(t, std::true_type{});
+        if (TAG) step_tagged(t); else step(t, std::true_type{});
         if ((k & 7) == 7) {
 #pragma unroll
             for (int q = 0; q < QD; q++) {
@@ -498,11 +563,11 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 // ---------------------------------------------------------------------------
 // Column layout policy of the packed pass: how a tile's columns map to (lane, slot),
 // which pass / loader go with it, and where the walker finds a cell's pointer word.
-template <int C, int LANES = kGroup> struct UniformLayout {
+template <int C, int LANES = kGroup, bool TAG = false> struct UniformLayout {
     using G = GeometryP16<C, LANES>;
     static constexpr int kLanes = LANES;                          // lanes per tile pair
     static constexpr int kSlotsPerLane = C;
-    static constexpr int kWalkCols = C, kWalkQuads = G::kQuads, kWalkFmt = 1;   // for the walker
+    static constexpr int kWalkCols = C, kWalkQuads = G::kQuads, kWalkFmt = TAG ? 2 : 1;   // for the walker
     static constexpr int kRow0 = LANES;                           // ref stream entry of (delay 0, row 1)
     // register budget: 32 columns per lane need a whole SIMD's file
     static constexpr int kBlocksPerCu = C <= 20 ? 3 : 1;
@@ -515,7 +580,7 @@ template <int C, int LANES = kGroup> struct UniformLayout {
     template <bool RAW>
     __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C], int T_end,
                                 int tB, uint32_t *wsA, uint32_t *wsB)
-    { dp_pass_p16<C, false, RAW, LANES>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    { dp_pass_p16<C, false, RAW, LANES, TAG>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
     // start cell (R, Q) of the traceback: lane, column in lane, stored step (tB_tile = tile's own first stored step)
     __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
     { l = (Q - 1) / C; c = (Q - 1) - l * C; k = R + l - tB_tile; }
@@ -526,6 +591,7 @@ template <int C, int LANES = kGroup> struct UniformLayout {
 // pair on 32 lanes with 10 columns each -- half the instructions per step, so a chain advances about twice as
 // fast, at 2 % more instructions per cell (both regions of a lane pay for pointers) and half as many tiles per wave.
 using WideLayout = UniformLayout<10, 32>;
+using WideLayoutTagged = UniformLayout<10, 32, true>;
 
 // ---------------------------------------------------------------------------
 // Persistent main kernel: every group carries two candidates (slot A / slot B).

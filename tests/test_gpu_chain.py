@@ -78,7 +78,7 @@ def test_kernel_family_is_the_one_asked_for(kernel_family):
                             "packed16-wide": "packed16-wide", "int32-seed": "packed16-split",
                             "int32": "int32"}[kernel_family]
     assert st["seed_layout"] == ("packed16" if kernel_family.startswith("packed16") else "int32")
-    assert st["tagged_pointers"] == (kernel_family in ("packed16", "int32-seed"))
+    assert st["tagged_pointers"] == (kernel_family not in ("packed16-plain", "int32"))
     if st["packed16"]:
         assert 0 < st["handed_off"] <= len(cf) and st["seed_cells"] > 0
     eng.close()

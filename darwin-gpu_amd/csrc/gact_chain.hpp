@@ -216,11 +216,10 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
-        } else if (FMT == 2) {
+        } else if (FMT == 2) {                                   // taken as it is: the walk runs on this numbering
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
-            const uint32_t op = v & 3u;                          // align.h:23 numbering Z0 D1 I2 M3
-            code = op ? 4u - op : 0u;
-            flags = (~v >> 16) & 3u;
+            code = v & 3u;
+            flags = (v >> 16) & 3u;
         } else {
             const uint32_t nib = w >> ((~(uint32_t)k & 7u) * 4u);
             const uint32_t op = nib & 3u;                        // align.h:23 numbering Z0 D1 I2 M3
@@ -233,13 +232,17 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         refill(l0, c0, k0);
         fetch(l0, c0, k0, cur, fl);
     }
-    if (left && !wk.have_left && cur != 0) { wk.have_left = 1; wk.left_first_gap = cur != 1; }
+    // state numbering of the walk: FMT 0 / 1 words are turned into the packed kernel's op codes (1 MATCH 2 INSERT
+    // 3 DELETE, flag set = the gap goes on); FMT 2 words carry align.h:23 numbering (3 MATCH 2 INSERT 1 DELETE) and
+    // flags that say the opposite (set = the gap was opened here), and the walk uses them as they are
+    constexpr uint32_t kM = FMT == 2 ? 3u : 1u, kI = 2u, kD = FMT == 2 ? 1u : 3u;
+    if (left && !wk.have_left && cur != 0) { wk.have_left = 1; wk.left_first_gap = cur != kM; }
     // conditions live as lane masks on the scalar unit; a counter takes one as the carry of a single VALU op
     const uint64_t left_m = lanes(left);
     uint64_t gprev = lanes(left ? wk.pend_gap != 0 : wk.open_flag == 0);
     for (int it = 0; cur != 0; it++) {
         // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209)
-        const uint64_t g = lanes(cur != 1);
+        const uint64_t g = lanes(cur != kM);
         const uint64_t eq = lanes(ra[nis * rstride] == qa[njs]);
         n_ext = add_lane_bit(n_ext, gprev & g);
         n_open = add_lane_bit(n_open, (gprev ^ g) & ((left_m & gprev) | (~left_m & g)));
@@ -247,9 +250,9 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         n_eq = add_lane_bit(n_eq, ~g & eq);
         gprev = (gprev & ~lanes(true)) | g;                       // walkers that have stopped keep their last column
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
-        nis = sub_lane_bit(nis, lanes(cur != 3));
-        njs = sub_lane_bit(njs, lanes(cur != 2));
-        const uint32_t forced = (fl & (4u - cur)) ? cur : 1u;
+        nis = sub_lane_bit(nis, lanes(cur != kD));
+        njs = sub_lane_bit(njs, lanes(cur != kI));
+        const uint32_t forced = FMT == 2 ? ((fl & cur) ? kM : cur) : ((fl & (4u - cur)) ? cur : kM);
         // (a walker that is about to stop may have left the tile: keep its addresses inside the stored window)
         const int p = imax(p0 + njs, 0);
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
@@ -258,7 +261,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         if ((it & 7) == 7) refill(l, c, k);
         uint32_t code;
         fetch(l, c, k, code, fl);
-        const uint32_t nxt = cur == 1 ? code : forced;
+        const uint32_t nxt = cur == kM ? code : forced;
         cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
     }
     ref_steps = -nis; query_steps = -njs; nst = -nis - njs - n_m;

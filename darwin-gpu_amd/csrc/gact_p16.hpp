@@ -1,16 +1,19 @@
-// gact_p16.hpp -- packed-int16 variant of the chain kernel's DP pass.
+// gact_p16.hpp -- the packed-int16 chain kernels: DP pass, loaders, column layouts, main and seed launch.
 //
-// Same decomposition as gact_device.hpp (16 lanes per tile, C columns per
-// lane, anti-diagonal wavefront, DPP row_shr across lanes), but every 32-bit
-// register carries TWO tiles: tile A in the low half-word, tile B in the high
-// one, so a wave works on 8 tiles and each score instruction (v_pk_add_i16,
-// v_pk_max_i16, v_pk_mad_i16) serves two cells.  The traceback-pointer masks
-// still come from one compare per cell, now SDWA half-word compares
-// (v_cmp_*_i16_sdwa src_sel:WORD_0/1).
+// Same decomposition as gact_device.hpp (a tile per group of lanes, C columns per lane, anti-diagonal wavefront,
+// DPP moves across lanes), but every 32-bit register carries TWO tiles: tile A in the low half-word, tile B in
+// the high one, so a wave works on 8 tiles (4 in the wide layout) and each score instruction (v_pk_add_i16,
+// v_pk_max_i16, v_perm_b32 ...) serves two cells.  Pointer bits are built arithmetically for both tiles at once
+// (no lane masks); where the scoring allows it the pointer phase runs on tagged scores and the recurrence's own
+// max operations deliver them (TAG).
 //
-// Valid only while every intermediate fits int16 (p16_scoring_ok); the engine
-// falls back to the int32 kernel otherwise.  No arg-max here: first tiles are
-// done by the int32 kernel's seed launch (gact_kernels.hpp).
+//   dp_pass_p16        uniform column layout (16 or 32 lanes per tile pair), with the arg-max variant for first tiles
+//   dp_pass_p16s       split two-region layout (gact_p16s.hpp): the one that runs at the reference's parameters
+//   extend_p16_kernel  persistent main launch over a layout policy (UniformLayout / SplitLayout / WideLayout)
+//   seed_p16_kernel    first tiles, then hand-off to the main launch
+//
+// Valid only while every intermediate fits int16 (p16_scoring_ok, p16_argmax_ok, p16_tagged_ok); the engine
+// falls back step by step (explicit pointer comparisons, int32 seed kernel, int32 chain kernel) otherwise.
 #pragma once
 
 #include <type_traits>

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(kBlockThreads, 3) void align_tiles_kernel(
 //
 // seed_mode: walk every candidate only until its first tile has been consumed
 // (first_tile == false) or the chain is over, then hand the chain state to the
-// main launch (ChainQueues).  The packed-int16 main kernel has no arg-max path;
-// this kernel does all first tiles for it.
+// main launch (ChainQueues): the seed launch of the packed main kernel where the
+// packed arg-max keys do not fit (seed_p16_kernel otherwise).
 template <int C>
 __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
     KParams kp, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,

@@ -17,8 +17,8 @@
 // lane 0 starts that row of region 2, so region 1's last column reaches
 // region 2's first one with the same one-step DPP hop as any other lane
 // boundary (row_ror:1 instead of row_shr:1).  Pointer work is emitted for the
-// C2 region-2 slots only: 7 x 12.5 + 13 x 26.5 instead of 20 x 26.5
-// instructions per step in the window phase, for 16 more steps per pass.
+// C2 region-2 slots only: per step of the window phase 7 x 11 + 13 x 25 (22 on
+// tagged scores) instead of 20 x 25 slot instructions, for 16 more steps per pass.
 //
 // Same cells, same arithmetic as dp_pass_p16 -- only the schedule differs.
 #pragma once

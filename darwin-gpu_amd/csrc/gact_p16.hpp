@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "gact_chain.hpp"
+#include "gact_kernels.hpp"      // WaveCtx, first_pointer_step, last_step
 
 namespace gact {
 

@@ -139,9 +139,12 @@ int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int3
     int rc = check_slot(e, slot);
     if (rc) return rc;
     if (!n_forward || !n_reverse) return fail(GACT_HIP_EINVAL, "dsoft_query: NULL argument");
+    std::lock_guard<std::mutex> lk0(e->upload_mu);      // the sets must not change under the query (same order as dsoft_build)
     std::lock_guard<std::mutex> lk(e->dsoft_mu);
     DsoftState &d = e->dsoft;
-    if (!d.built) return fail(GACT_HIP_EINVAL, "dsoft_query: gact_hip_dsoft_build has not been called");
+    if (!d.built)
+        return fail(GACT_HIP_EINVAL, "dsoft_query: no index for the resident GACT_SET_REF (gact_hip_dsoft_build has not "
+                                     "been called since it was uploaded)");
     const SeqSet &rs = e->sets[GACT_SET_REF], &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
     if (qf.n == 0 || qr.n != qf.n) return fail(GACT_HIP_EINVAL, "dsoft_query: both query sets must be uploaded");
     if (first_query < 0 || n_queries < 0 || (int64_t)first_query + n_queries > qf.n)
@@ -226,6 +229,7 @@ int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int3
     if (run > 0x7fffffff) return fail(GACT_HIP_ERANGE, "dsoft_query: %lld candidates do not fit one launch", (long long)run);
     *n_reverse = (int32_t)run - *n_forward;
     const size_t n = (size_t)run;
+    sl.n_cands = 0; sl.h_cands.clear(); sl.checked_key[0] = -1;
     if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve(n * gact::kBuckets) || sl.chain_states.reserve(n))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     HIP_TRY(hipMemcpyAsync(d.out_base.p, base.data(), (size_t)n_tasks * sizeof(int64_t), hipMemcpyHostToDevice, sl.stream));
@@ -234,6 +238,7 @@ int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int3
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
+    sl.n_cands = n;
     if (query_ms) HIP_TRY(hipEventElapsedTime(query_ms, sl.ev0, sl.ev1));
     return 0;
 }
@@ -243,8 +248,8 @@ int gact_hip_candidates_download(gact_hip_engine *e, int slot, int32_t n, gact_c
     int rc = check_slot(e, slot);
     if (rc) return rc;
     Slot &sl = e->slots[slot];
-    if (n < 0 || (size_t)n > sl.cands.cap || (n > 0 && !out))
-        return fail(GACT_HIP_EINVAL, "candidates_download: bad arguments");
+    if (n < 0 || (size_t)n > sl.n_cands || (n > 0 && !out))
+        return fail(GACT_HIP_EINVAL, "candidates_download: bad arguments (slot %d holds %zu candidates)", slot, sl.n_cands);
     if ((rc = set_device(e))) return rc;
     if (n) HIP_TRY(hipMemcpyAsync(out, sl.cands.p, (size_t)n * sizeof(gact_candidate), hipMemcpyDeviceToHost, sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));

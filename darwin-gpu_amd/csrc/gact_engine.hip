@@ -105,6 +105,10 @@ struct Slot {
     DevBuf<gact_tile_result> results;
     DevBuf<uint8_t> states;
     DevBuf<gact_candidate> cands;
+    size_t n_cands = 0;                  // candidates the slot really holds (uploaded, or produced by the device filter)
+    std::vector<gact_candidate> h_cands; // host copy of an uploaded list, for the strand-aware position check at run time;
+                                         // empty for lists the device filter made (valid by construction)
+    int64_t checked_key[4] = {-1, -1, -1, -1};   // {first, n, rc_from, sets_epoch} of the last range that passed the check
     DevBuf<gact_overlap> overlaps;
     int *d_counter = nullptr;            // see queues()
     DevBuf<int> live;
@@ -175,6 +179,7 @@ struct gact_hip_engine {
     SeqSet sets[GACT_NUM_SETS];
     std::vector<Slot> slots;
     std::mutex upload_mu;
+    int64_t sets_epoch = 0;     // bumped by every upload / derive_revcomp: range checks of older sets are void
     DsoftState dsoft;
     std::mutex dsoft_mu;        // the filter's scratch is shared by all slots
 };
@@ -573,6 +578,12 @@ int gact_hip_upload_seqs(gact_hip_engine *e, int which, const uint8_t *concat, c
     std::lock_guard<std::mutex> lk(e->upload_mu);
     int rc = set_device(e);
     if (rc) return rc;
+    e->sets_epoch++;
+    if (which == GACT_SET_REF) {
+        // the filter's index (start bins, bin -> sequence map, positions) describes the set it was built from
+        std::lock_guard<std::mutex> lk2(e->dsoft_mu);
+        e->dsoft.built = false;
+    }
     return upload_set(e, e->sets[which], e->slots[0], concat, offsets, n_seqs);
 }
 
@@ -586,6 +597,7 @@ int gact_hip_derive_revcomp(gact_hip_engine *e)
     SeqSet &qr = e->sets[GACT_SET_QUERY_RC];
     if (qf.n == 0 || !qf.d_raw) return fail(GACT_HIP_EINVAL, "derive_revcomp: GACT_SET_QUERY has not been uploaded");
     Slot &sl = e->slots[0];
+    e->sets_epoch++;
     if ((rc = reserve_set(qr, qf.total, qf.n))) return rc;
     qr.h_offsets = qf.h_offsets; qr.n = qf.n; qr.total = qf.total; qr.max_len = qf.max_len;
     HIP_TRY(hipMemcpyAsync(qr.d_offsets, qf.d_offsets, qf.h_offsets.size() * sizeof(int64_t), hipMemcpyDeviceToDevice,
@@ -683,17 +695,42 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
             return fail(GACT_HIP_ERANGE, "candidate %d: sequence id out of range", k);
         const int64_t rl = rs.h_offsets[c.ref_id + 1] - rs.h_offsets[c.ref_id];
         // darwin.cpp:222-224 clamps ref_pos to the read length; positions beyond
-        // the reads would make GACT slice outside them
-        const SeqSet &qv = (c.query_id < qf.n) ? qf : qr;
-        const int64_t ql = qv.h_offsets[c.query_id + 1] - qv.h_offsets[c.query_id];
-        if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0 || c.query_pos > ql)
+        // the reads would make GACT slice outside them.  query_pos is checked by
+        // candidates_run*, which knows the strand and so the set the candidate reads
+        if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0)
             return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
     }
     if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve((size_t)n * gact::kBuckets) || sl.chain_states.reserve(n))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
+    sl.n_cands = 0;
+    sl.h_cands.assign(cands, cands + n);
+    sl.checked_key[0] = -1;
     if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, cands, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
                                   sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
+    sl.n_cands = (size_t)n;
+    return 0;
+}
+
+// candidates [first, first+n) of an uploaded list against the sets this run will read them from
+// (index >= rc_from: GACT_SET_QUERY_RC); remembered, so that repeated runs of one range check once
+static int check_candidate_range(gact_hip_engine *e, Slot &sl, int32_t first, int32_t n, int32_t rc_from)
+{
+    if (sl.h_cands.empty()) return 0;                 // made by the device filter from these very sets
+    const int64_t key[4] = {first, n, rc_from, e->sets_epoch};
+    if (!memcmp(key, sl.checked_key, sizeof key)) return 0;
+    const SeqSet &rs = e->sets[GACT_SET_REF];
+    for (int32_t k = first; k < first + n; k++) {
+        const gact_candidate &c = sl.h_cands[(size_t)k];
+        const SeqSet &qs = e->sets[k >= rc_from ? GACT_SET_QUERY_RC : GACT_SET_QUERY];
+        if (c.ref_id >= rs.n || c.query_id >= qs.n)
+            return fail(GACT_HIP_ERANGE, "candidate %d: sequence id out of range", k);
+        const int64_t rl = rs.h_offsets[c.ref_id + 1] - rs.h_offsets[c.ref_id];
+        const int64_t ql = qs.h_offsets[c.query_id + 1] - qs.h_offsets[c.query_id];
+        if (c.ref_pos > rl || c.query_pos > ql)
+            return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
+    }
+    memcpy(sl.checked_key, key, sizeof key);
     return 0;
 }
 
@@ -703,13 +740,15 @@ int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, i
     int rc = check_slot(e, slot);
     if (rc) return rc;
     Slot &sl = e->slots[slot];
-    if (first < 0 || n < 0 || (size_t)first + (size_t)n > sl.cands.cap)
-        return fail(GACT_HIP_EINVAL, "candidates_run: range [%d,%d) not uploaded", first, first + n);
+    if (first < 0 || n < 0 || (size_t)first + (size_t)n > sl.n_cands)
+        return fail(GACT_HIP_EINVAL, "candidates_run: range [%d,%d) outside the %zu candidates of slot %d", first,
+                    first + n, sl.n_cands, slot);
     if ((rc = set_device(e))) return rc;
     const bool need_f = first < rc_from, need_r = first + n > rc_from;
     if (n > 0 && (e->sets[GACT_SET_REF].n == 0 || (need_f && e->sets[GACT_SET_QUERY].n == 0) ||
                   (need_r && e->sets[GACT_SET_QUERY_RC].n == 0)))
         return fail(GACT_HIP_EINVAL, "candidates_run: read sets not uploaded");
+    if ((rc = check_candidate_range(e, sl, first, n, rc_from))) return rc;
     HIP_TRY(hipMemsetAsync(sl.d_counter, 0, kCounterInts * sizeof(int), sl.stream));
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
     sl.two_phase = false;
@@ -739,8 +778,8 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
     int rc = check_slot(e, slot);
     if (rc) return rc;
     Slot &sl = e->slots[slot];
-    if (n < 0 || (size_t)n > sl.overlaps.cap || (n > 0 && !out))
-        return fail(GACT_HIP_EINVAL, "candidates_fetch: bad arguments");
+    if (n < 0 || (size_t)n > sl.n_cands || (n > 0 && !out))
+        return fail(GACT_HIP_EINVAL, "candidates_fetch: bad arguments (slot %d holds %zu candidates)", slot, sl.n_cands);
     if ((rc = set_device(e))) return rc;
     if ((size_t)n > sl.h_records_cap) {
         if (sl.h_records) (void)hipHostFree(sl.h_records);

@@ -243,7 +243,10 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
 // ---------------------------------------------------------------------------
 // 2-bit packer: 16 bases -> one word; flags[0] |= 1 when a byte is not A/C/G/T
 // (or the GPU build's 0..3 recode, darwin.cpp:320-332).  Code order A0 C1 G2 T3
-// as ntcoding.h:25-28.
+// as ntcoding.h:25-28.  The image follows NtToTwoBit (ntcoding.cpp:57-70) for every
+// byte -- lower case decodes like upper case, anything else is A -- because the seed
+// filter reads the queries from it; a set holding such bytes is flagged, and GACT then
+// compares its raw bytes (align.cpp:134: case matters, N == N) and never this image.
 __device__ __forceinline__ uint32_t base_code(uint32_t b, bool &bad)
 {
     switch (b) {
@@ -251,6 +254,10 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b, bool &bad)
         case 'C': case 1: return 1;
         case 'G': case 3: return 2;
         case 'T': case 2: return 3;
+        case 'a': bad = true; return 0;
+        case 'c': bad = true; return 1;
+        case 'g': bad = true; return 2;
+        case 't': bad = true; return 3;
         default: bad = true; return 0;
     }
 }

@@ -2,6 +2,7 @@
 //
 //   darwin_hip <REF.fasta> <READS.fasta> CPU_THREADS [--params params.cfg]
 //              [--candidates FILE | --dump-candidates FILE [--dsoft-only]] [--device-dsoft]
+//              [--device D] [--shard R/W] [--recode]
 //
 // Plays the part of reference darwin.cpp:451-646 for the GACT stage: owns the
 // globals gact.cpp reads, loads params.cfg and the two FASTA files, builds the
@@ -17,7 +18,14 @@
 // --device-dsoft runs the filter on the GPU as well (gact_hip_dsoft_build / _query): every feeder thread
 // filters its read range straight into its slot's device candidate array and extends it from there.
 //
-//   darwin_hip --selftest FILE   exercises AlignWithBT / Align_Batch_GPU / GACT
+// --device D: the GPU this process uses (the reference is single-device, cuda_host.cu:195).  --shard R/W: this
+// process is rank R of W -- it extends every W-th candidate (host filter) or the R-th contiguous range of reads
+// (--device-dsoft) and writes darwin.<R>.<thread>.out; the union of all ranks' files is the W = 1 output, and the
+// reference's canonical form `cat darwin.*.out | sort | uniq` (README:25) is the gather.  --recode: hand the
+// read sets to GACT_Batch the way the reference's -DGPU build does, recoded in place to A0 C1 T2 G3
+// (darwin.cpp:314-398).  Stage timers are printed with the reference's labels (darwin.cpp:300,405,441,553-639).
+//
+//   darwin_hip --selftest FILE   exercises AlignWithBT / Align_Batch / Align_Batch_GPU / GACT
 //                                on the cases in FILE and prints what they return.
 #include <cmath>
 #include <cstdio>
@@ -25,7 +33,9 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <chrono>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -121,9 +131,37 @@ static std::map<std::string, double> parse_cfg(const std::string &path)
 
 struct Cand { int ref_id, query_id, ref_pos, query_pos, comp; };
 
+// ---- stage timers with the reference's labels (darwin.cpp:300,405,441 per thread; :553,574,596,639 in main)
+static std::mutex io_lock;
+typedef std::chrono::steady_clock::time_point Tick;
+static Tick now() { return std::chrono::steady_clock::now(); }
+static void print_stage(const char *label, Tick a, Tick b)
+{
+    const long ms = (long)(std::chrono::duration<double, std::milli>(b - a).count() + 0.5);
+    std::lock_guard<std::mutex> lk(io_lock);
+    std::cout << label << ": " << ms << " msec" << std::endl;
+}
+
+static int shard_rank = 0, shard_world = 1;
+static std::string out_name(int cpu_id)
+{
+    // darwin.cpp:174; ranks of a sharded run keep their files apart
+    return shard_world > 1 ? "darwin." + std::to_string(shard_rank) + "." + std::to_string(cpu_id) + ".out"
+                           : "darwin." + std::to_string(cpu_id) + ".out";
+}
+
+// darwin.cpp:314-398: the -DGPU build recodes every base in place before GACT_Batch; anything else stays
+static void recode_in_place(std::vector<std::string> &seqs)
+{
+    for (std::string &r : seqs)
+        for (char &c : r)
+            switch (c) { case 'A': c = 0; break; case 'C': c = 1; break; case 'T': c = 2; break; case 'G': c = 3; break; default: break; }
+}
+
 static void feeder(int cpu_id, const std::vector<Cand> *all, size_t lo, size_t hi, GPU_storage s)
 {
-    std::ofstream fout("darwin." + std::to_string(cpu_id) + ".out");
+    std::ofstream fout(out_name(cpu_id));
+    const Tick t0 = now();
     std::vector<GACT_call> calls_for, calls_rev;
     for (size_t k = lo; k < hi; k++) {
         const Cand &c = (*all)[k];
@@ -138,19 +176,23 @@ static void feeder(int cpu_id, const std::vector<Cand> *all, size_t lo, size_t h
     GACT_Batch(calls_rev, (int)calls_rev.size(), true, (int)calls_for.size(), &s, match_score, mismatch_score,
                gap_open, gap_extend, fout);
     fout.close();
+    print_stage("Time GACT calling", t0, now());                 // darwin.cpp:441
 }
 
 // --device-dsoft: reads [lo, hi) are filtered and extended on the device, slot s.slot
 static void device_feeder(int cpu_id, int lo, int hi, GPU_storage s, std::vector<Cand> *dump)
 {
     gact_hip_engine *e = (gact_hip_engine *)s.engine;
-    std::ofstream fout("darwin." + std::to_string(cpu_id) + ".out");
+    std::ofstream fout(out_name(cpu_id));
     int32_t nf = 0, nr = 0;
     float ms = 0;
     auto check = [](int rc, const char *what) {
         if (rc != 0) { printf("\n%s failed: %s\n\n", what, gact_hip_last_error()); exit(-1); }
     };
+    const Tick t0 = now();
     check(gact_hip_dsoft_query(e, s.slot, lo, hi - lo, &nf, &nr, &ms), "gact_hip_dsoft_query");
+    const Tick t1 = now();
+    print_stage("Time finding seeds", t0, t1);                   // darwin.cpp:300
     const int32_t n = nf + nr;
     if (dump) {
         std::vector<gact_candidate> c((size_t)n);
@@ -168,6 +210,7 @@ static void device_feeder(int cpu_id, int lo, int hi, GPU_storage s, std::vector
                                                 reads_descrips[r.query_id][0].c_str(), line, sizeof line);
         fout.write(line, len);
     }
+    print_stage("Time GACT calling", t1, now());                 // darwin.cpp:441
 }
 
 static void upload_set(gact_hip_engine *e, int which, const std::vector<std::string> &seqs)
@@ -228,6 +271,28 @@ static int selftest(const char *path)
                 printf("\n");
                 free(out);
             }
+        } else if (kind == "P") {
+            // P ref query match mismatch open ext reverse first early ref_pos query_pos -> AlignWithBT at a position
+            std::string r, q; int m, x, o, e, rev, first, early, rp, qp;
+            in >> r >> q >> m >> x >> o >> e >> rev >> first >> early >> rp >> qp;
+            print_queue("AlignWithBT", AlignWithBT((char *)r.c_str(), (long long)r.size(), (char *)q.c_str(),
+                                                   (long long)q.size(), m, x, o, e, qp, rp, rev != 0, first != 0, early));
+        } else if (kind == "B") {
+            // B n match mismatch open ext early, then n lines "ref query reverse first" ("-" "-" = idle, ref_len -1)
+            int nb, m, x, o, e, early;
+            in >> nb >> m >> x >> o >> e >> early;
+            std::vector<std::string> rs(nb), qs(nb);
+            std::vector<int> rl(nb), ql(nb);
+            std::vector<char> rv(nb), fs(nb);
+            for (int k = 0; k < nb; k++) {
+                int rev, first;
+                in >> rs[k] >> qs[k] >> rev >> first;
+                if (rs[k] == "-") { rs[k].clear(); qs[k].clear(); rl[k] = -1; ql[k] = 0; }     // align.cpp:40-44
+                else { rl[k] = (int)rs[k].size(); ql[k] = (int)qs[k].size(); }
+                rv[k] = (char)rev; fs[k] = (char)first;
+            }
+            std::vector<std::queue<int> > res = Align_Batch(rs, qs, rl, ql, m, x, o, e, rl, ql, rv, fs, early);
+            for (int k = 0; k < nb; k++) print_queue("Align_Batch", res[k]);
         } else if (kind == "G") {
             std::string r, q; int rp, qp, t, ov, thr, m, x, o, e, comp;
             in >> r >> q >> rp >> qp >> t >> ov >> thr >> m >> x >> o >> e >> comp;
@@ -257,14 +322,21 @@ int main(int argc, char *argv[])
         return 1;
     }
     std::string cand_path, dump_path, cfg_path = "params.cfg";
-    bool dsoft_only = false, device_dsoft = false;
+    bool dsoft_only = false, device_dsoft = false, recode = false;
     for (int a = 4; a < argc; a++) {
         if (!strcmp(argv[a], "--candidates") && a + 1 < argc) cand_path = argv[++a];
         else if (!strcmp(argv[a], "--dump-candidates") && a + 1 < argc) dump_path = argv[++a];
         else if (!strcmp(argv[a], "--params") && a + 1 < argc) cfg_path = argv[++a];
         else if (!strcmp(argv[a], "--dsoft-only")) dsoft_only = true;
         else if (!strcmp(argv[a], "--device-dsoft")) device_dsoft = true;
+        else if (!strcmp(argv[a], "--recode")) recode = true;
+        else if (!strcmp(argv[a], "--device") && a + 1 < argc) setenv("GACT_HIP_DEVICE", argv[++a], 1);   // read by GPU_init
+        else if (!strcmp(argv[a], "--shard") && a + 1 < argc) {
+            if (sscanf(argv[++a], "%d/%d", &shard_rank, &shard_world) != 2 || shard_world < 1 || shard_rank < 0 ||
+                shard_rank >= shard_world) { fprintf(stderr, "--shard wants R/W with 0 <= R < W\n"); return 1; }
+        } else { fprintf(stderr, "unknown option %s\n", argv[a]); return 1; }
     }
+    if (recode && device_dsoft) { fprintf(stderr, "--recode: the device filter reads ASCII sets\n"); return 1; }
     std::map<std::string, double> cfg = parse_cfg(cfg_path);
     auto get = [&](const char *k, int dflt) { return cfg.count(k) ? (int)cfg[k] : dflt; };
     match_score = get("GACT_scoring/match", 1); mismatch_score = get("GACT_scoring/mismatch", -1);
@@ -285,11 +357,15 @@ int main(int argc, char *argv[])
     printf("Scores: match = %d, mismatch = %d, gap_open = %d, gap_extend = %d\n", match_score, mismatch_score,
            gap_open, gap_extend);
 
+    Tick t_stage = now();
     parse_fasta(ref_path, reference_descrips, reference_seqs, reference_lengths);
+    print_stage("Time elapsed (loading reference genome)", t_stage, now());      // darwin.cpp:553
+    t_stage = now();
     parse_fasta(reads_path, reads_descrips, reads_seqs, reads_lengths);
     if (!device_dsoft)
         for (const std::string &r : reads_seqs) rev_reads_seqs.push_back(rev_comp(r));
     std::cout << "Number of reads: " << reads_seqs.size() << std::endl;
+    print_stage("Time elapsed (loading reads)", t_stage, now());                 // darwin.cpp:574
 
     if (device_dsoft) {
         std::vector<GPU_storage> s;
@@ -302,19 +378,27 @@ int main(int argc, char *argv[])
         gact_dsoft_params gp = {dp.seed_size, (int32_t)dp.bin_size, (int32_t)dp.window_size, dp.threshold, dp.num_seeds,
                                 (int32_t)dp.seed_occurence_multiple, dp.max_candidates};
         gact_dsoft_info info;
+        t_stage = now();
         if (gact_hip_dsoft_build(e, &gp, &info) != 0) { printf("\ndsoft_build failed: %s\n\n", gact_hip_last_error()); return 1; }
         printf("Reference length: %lld, %zu pieces; device index: %lld minimizers, %.1f ms\n", (long long)info.ref_length,
                reference_seqs.size(), (long long)info.n_minimizers, info.build_ms);
-        const int num_reads = (int)reads_seqs.size();
+        print_stage("Time elapsed (seed position table construction)", t_stage, now());      // darwin.cpp:596
+        // this rank's contiguous share of the reads, then contiguous ranges per feeder thread (darwin.cpp:619-629)
+        const int all_reads = (int)reads_seqs.size();
+        const int per_rank = (int)std::ceil(1.0 * all_reads / shard_world);
+        const int r_lo = std::min(all_reads, shard_rank * per_rank), r_hi = std::min(all_reads, r_lo + per_rank);
+        const int num_reads = r_hi - r_lo;
         const int reads_per_thread = (int)std::ceil(1.0 * num_reads / num_threads);
         std::vector<std::vector<Cand> > dumps(num_threads);
         const bool dumping = !dump_path.empty() && dsoft_only;
         std::vector<std::thread> threads;
+        t_stage = now();
         for (int i = 0; i < num_threads; i++) {
-            const int lo = std::min(num_reads, i * reads_per_thread), hi = std::min(num_reads, lo + reads_per_thread);
+            const int lo = r_lo + std::min(num_reads, i * reads_per_thread), hi = std::min(r_hi, lo + reads_per_thread);
             threads.push_back(std::thread(device_feeder, i, lo, hi, s[i], dumping ? &dumps[i] : nullptr));
         }
         for (auto &t : threads) t.join();
+        print_stage("Time elapsed (seed table querying + aligning)", t_stage, now());         // darwin.cpp:639
         if (dumping) {
             std::ofstream out(dump_path, std::ios::binary);
             size_t total = 0;
@@ -327,6 +411,7 @@ int main(int argc, char *argv[])
 
     // per-thread candidate lists, contiguous read ranges like darwin.cpp:619-629
     std::vector<std::vector<Cand> > per_thread(num_threads);
+    Tick t_query = now();
     if (!cand_path.empty()) {
         std::vector<Cand> cands;
         std::ifstream in(cand_path, std::ios::binary);
@@ -340,13 +425,17 @@ int main(int argc, char *argv[])
         }
     } else {
         DsoftIndex index;
+        t_stage = now();
         index.build(reference_seqs, dp);
         printf("Reference length: %u, %zu pieces\n", index.reference_length(), reference_seqs.size());
+        print_stage("Time elapsed (seed position table construction)", t_stage, now());      // darwin.cpp:596
+        t_query = now();
         const int num_reads = (int)reads_seqs.size();
         const int reads_per_thread = (int)std::ceil(1.0 * num_reads / num_threads);
         std::vector<std::thread> filt;
         for (int i = 0; i < num_threads; i++) {
             filt.push_back(std::thread([&, i] {
+                const Tick t0 = now();
                 const int lo = std::min(num_reads, i * reads_per_thread), hi = std::min(num_reads, lo + reads_per_thread);
                 DsoftScratch sc;
                 std::vector<DsoftCandidate> f, r;
@@ -357,6 +446,7 @@ int main(int argc, char *argv[])
                     for (const DsoftCandidate &c : f) per_thread[i].push_back(Cand{c.ref_id, c.query_id, c.ref_pos, c.query_pos, 0});
                     for (const DsoftCandidate &c : r) per_thread[i].push_back(Cand{c.ref_id, c.query_id, c.ref_pos, c.query_pos, 1});
                 }
+                print_stage("Time finding seeds", t0, now());            // darwin.cpp:300
             }));
         }
         for (auto &t : filt) t.join();
@@ -369,6 +459,25 @@ int main(int argc, char *argv[])
         for (auto &v : per_thread) out.write((const char *)v.data(), (std::streamsize)(v.size() * sizeof(Cand)));
     }
     if (dsoft_only) return 0;
+    if (shard_world > 1) {
+        // this rank's share: every W-th candidate of the whole list (chain lengths vary widely),
+        // dealt out again in contiguous ranges to its feeder threads
+        std::vector<Cand> mine;
+        size_t g = 0;
+        for (auto &v : per_thread)
+            for (const Cand &c : v)
+                if ((int)(g++ % (size_t)shard_world) == shard_rank) mine.push_back(c);
+        const size_t per = (mine.size() + num_threads - 1) / num_threads;
+        for (int i = 0; i < num_threads; i++) {
+            const size_t lo = std::min(mine.size(), i * per), hi = std::min(mine.size(), lo + per);
+            per_thread[i].assign(mine.begin() + lo, mine.begin() + hi);
+        }
+    }
+    if (recode) {
+        const Tick t0 = now();
+        recode_in_place(reference_seqs); recode_in_place(reads_seqs); recode_in_place(rev_reads_seqs);
+        print_stage("Time converting bases", t0, now());                          // darwin.cpp:405
+    }
 
     std::vector<GPU_storage> s;
     GPU_init(tile_size, tile_overlap, gap_open, gap_extend, match_score, mismatch_score, tile_size - tile_overlap,
@@ -377,6 +486,7 @@ int main(int argc, char *argv[])
     for (int i = 0; i < num_threads; i++)
         threads.push_back(std::thread(feeder, i, &per_thread[i], (size_t)0, per_thread[i].size(), s[i]));
     for (auto &t : threads) t.join();
+    print_stage("Time elapsed (seed table querying + aligning)", t_query, now());             // darwin.cpp:639
     GPU_close(&s, num_threads);
     return 0;
 }

@@ -69,6 +69,14 @@ void print_overlap(std::ofstream &fout, const gact_overlap &o)
     fout.flush();
 }
 
+// The reference is single-device (cudaSetDevice(0), cuda_host.cu:195).  One process per GPU is how this engine
+// scales: a launcher gives each process its GPU through GACT_HIP_DEVICE (darwin_hip --device sets it).
+int shim_device()
+{
+    const char *v = getenv("GACT_HIP_DEVICE");
+    return v ? atoi(v) : 0;
+}
+
 // small engines for the align.h / GACT() surface, keyed by what the kernels bake in
 typedef std::tuple<int, int, int, int, int, int, int> Key;   // tile, overlap, match, mismatch, open, ext, thr
 std::mutex g_side_mu;
@@ -83,7 +91,7 @@ gact_hip_engine *side_engine(int tile, int overlap, int match, int mismatch, int
     memset(&p, 0, sizeof p);
     p.tile_size = tile; p.tile_overlap = overlap;
     p.match = match; p.mismatch = mismatch; p.gap_open = open; p.gap_extend = ext;
-    p.first_tile_score_threshold = thr; p.device_id = 0; p.n_slots = 1;
+    p.first_tile_score_threshold = thr; p.device_id = shim_device(); p.n_slots = 1;
     gact_hip_engine *e = nullptr;
     SAFE(gact_hip_create(&p, &e));
     g_side[k] = e;
@@ -101,7 +109,7 @@ void GPU_init(int tile_size_, int tile_overlap_, int gap_open, int gap_extend, i
     p.tile_size = tile_size_; p.tile_overlap = tile_overlap_;
     p.match = match; p.mismatch = mismatch; p.gap_open = gap_open; p.gap_extend = gap_extend;
     p.first_tile_score_threshold = first_tile_score_threshold;
-    p.device_id = 0;                       // cuda_host.cu:195
+    p.device_id = shim_device();           // 0 like cuda_host.cu:195 unless GACT_HIP_DEVICE names another GPU
     p.n_slots = num_threads;
     SAFE(gact_hip_create(&p, &g_main.engine));
     g_main.params = p;
@@ -162,6 +170,12 @@ int *Align_Batch_GPU(std::vector<std::string> ref_seqs, std::vector<std::string>
         rl[t] = ref_lens[t];
         ql[t] = (ref_lens[t] == -1) ? 0 : query_lens[t];
         if (ref_lens[t] == -1) { rev[t] = 0; fst[t] = 0; continue; }
+        // the staging rows are tile_size wide (cuda_host.cu:56-61 sizes its own the same way)
+        if (rl[t] < 0 || rl[t] > stride || ql[t] < 0 || ql[t] > stride || (size_t)rl[t] > ref_seqs[t].size() ||
+            (size_t)ql[t] > query_seqs[t].size()) {
+            printf("\nAlign_Batch_GPU failed: tile %d has lengths %d x %d, tile_size is %d\n\n", t, rl[t], ql[t], tile_size_);
+            exit(-1);
+        }
         memcpy(rb.data() + (size_t)t * stride, ref_seqs[t].data(), (size_t)rl[t]);
         memcpy(qb.data() + (size_t)t * stride, query_seqs[t].data(), (size_t)ql[t]);
         // reverses[t]==1 (towards 0) keeps the bytes as they are, ==0 byte-reverses them
@@ -192,10 +206,28 @@ std::queue<int> AlignWithBT(char *ref_seq, long long int ref_len, char *query_se
                             int query_pos, int ref_pos, bool reverse, bool first, int early_terminate)
 {
     std::queue<int> q;
-    if (ref_len > GACT_HIP_MAX_TILE || query_len > GACT_HIP_MAX_TILE || ref_len < 0 || query_len < 0 ||
-        ref_pos != ref_len || query_pos != query_len) {
-        printf("\nAlignWithBT: tile %lld x %lld (pos %d,%d) outside what the HIP engine supports\n\n", ref_len,
-               query_len, ref_pos, query_pos);
+    if (ref_len < 0 || query_len < 0 || ref_pos < 0 || query_pos < 0) {
+        printf("\nAlignWithBT: negative length or position (%lld x %lld, pos %d,%d)\n\n", ref_len, query_len, ref_pos,
+               query_pos);
+        exit(-1);
+    }
+    if (!first) {
+        // (ref_pos, query_pos) is where pos_score is read and where the traceback starts (align.cpp:179-181,186).
+        // A cell depends on nothing below or right of it, so the answer is that of the tile cut down to ref_pos x
+        // query_pos: the first ref_pos bases in DP order, i.e. the slice's prefix, or its suffix when `reverse`
+        // (align.cpp:130-131).  On or beyond the border the pointer is ZERO (:101-107; cells past the tile are
+        // never written) and pos_score stays 0 (:104).
+        if (ref_pos == 0 || query_pos == 0 || ref_pos > ref_len || query_pos > query_len) {
+            q.push(0);
+            return q;
+        }
+        if (reverse) { ref_seq += ref_len - ref_pos; query_seq += query_len - query_pos; }
+        ref_len = ref_pos; query_len = query_pos;
+    }
+    if (ref_len > GACT_HIP_MAX_TILE || query_len > GACT_HIP_MAX_TILE) {
+        printf("\nAlignWithBT: tile %lld x %lld is larger than the HIP engine's %d (the reference allows %d, "
+               "align.cpp:66-67; no caller uses more than tile_size)\n\n", ref_len, query_len, GACT_HIP_MAX_TILE,
+               MAX_TILE_SIZE - 1);
         exit(-1);
     }
     std::lock_guard<std::mutex> lk(g_side_mu);

@@ -55,6 +55,7 @@ int oracle_align_with_bt(const char *ref_seq, long long ref_len,
     /* align.cpp:66-67 asserts */
     if (ref_len >= ORACLE_MAX_TILE_SIZE || query_len >= ORACLE_MAX_TILE_SIZE) return -2;
     if (ref_len < 0 || query_len < 0) return -2;
+    if (ref_pos < 0 || query_pos < 0 || ref_pos >= ORACLE_MAX_TILE_SIZE || query_pos >= ORACLE_MAX_TILE_SIZE) return -2;
 
     const int R = (int)ref_len, Q = (int)query_len;
     const size_t stride = (size_t)Q + 1;
@@ -143,7 +144,9 @@ int oracle_align_with_bt(const char *ref_seq, long long ref_len,
     } else {
         PUSH(pos_score);
     }
-    int state = dir[(size_t)i_curr * stride + j_curr] % 4;
+    /* align.cpp:85 zero-initialises the whole 2050 x 2050 matrix, and cells outside the tile are never
+     * written: a start position beyond the tile reads ZERO_OP (the stride here is the tile's own) */
+    int state = (i_curr > R || j_curr > Q) ? ORACLE_Z : dir[(size_t)i_curr * stride + j_curr] % 4;
     while (state != ORACLE_Z) {
         if (i_steps >= early_terminate || j_steps >= early_terminate) break;   /* :205 */
         PUSH(state);

@@ -127,3 +127,118 @@ def test_end_to_end_from_fasta_equals_reference_program(tmp_path):
             got += open(tmp_path / ("darwin.%d.out" % t)).read().splitlines()
         assert sorted(got) == e2e["lines_sorted"]
         assert len(got) > 40
+
+
+def test_align_batch_and_positions(oracle, tmp_path):
+    """Align_Batch (align.cpp:17-54: idle entries give an empty queue) and AlignWithBT called with
+    (ref_pos, query_pos) other than the tile's corner (align.cpp:179-181,186), both through the shim"""
+    import random
+    rng = random.Random(5150)
+    cases = [c for c in random_tiles(405, 30) if len(c[0]) and len(c[1])]
+    lines, want = [], []
+    # B: three batches, idle entries in between
+    for b in range(3):
+        sc = [(1, -1, -1, -1), (2, -3, -5, -2), (1, -1, -2, -1)][b]
+        early = (200, 64, 150)[b]
+        entries = []
+        for k in range(8):
+            if k in (1 + b, 6):
+                entries.append(None)
+            else:
+                entries.append(cases[(8 * b + k) % len(cases)])
+        lines.append("B %d %d %d %d %d %d" % (len(entries), *sc, early))
+        for e in entries:
+            if e is None:
+                lines.append("- - 0 0")
+                want.append([])
+            else:
+                a, q, rev, first = e
+                lines.append("%s %s %d %d" % (a.decode(), q.decode(), rev, first))
+                want.append(oracle.align_with_bt(a, q, sc, rev, first, early))
+    n_batch = len(want)
+    # P: positions inside, on the border of, and outside the tile
+    for k, (a, q, rev, first) in enumerate(cases):
+        R, Q = len(a), len(q)
+        for rp, qp in ((rng.randint(1, R), rng.randint(1, Q)), (R, rng.randint(1, Q)), (0, Q), (R, 0), (R + 1, Q),
+                       (R, Q)):
+            if k % 3 and (rp, qp) != (R, Q) and rp in (0, R + 1):
+                continue
+            sc = (1, -1, -1, -1) if k % 2 else (2, -3, -5, -2)
+            lines.append("P %s %s %d %d %d %d %d %d %d %d %d" % (a.decode(), q.decode(), *sc, rev, first, 200, rp, qp))
+            want.append(oracle.align_with_bt(a, q, sc, rev, first, 200, ref_pos=rp, query_pos=qp))
+    f = tmp_path / "cases.txt"
+    f.write_text("\n".join(lines) + "\n")
+    out = subprocess.run([_driver(), "--selftest", str(f)], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = [[int(x) for x in l.split()[1:]] for l in out.stdout.splitlines() if l.startswith(("Align_Batch ", "AlignWithBT"))
+           or l.strip() == "Align_Batch"]
+    assert len(got) == len(want) and n_batch == 24
+    assert got == want
+
+
+CFG_GACT = ("[GACT_scoring]\nmatch = 1\nmismatch = -1\ngap_open = -1\ngap_extend = -1\n"
+            "[GACT_first_tile]\nfirst_tile_size = 128\nfirst_tile_score_threshold = 35\n"
+            "[GACT_extend]\ntile_size = 320\ntile_overlap = 120\n")
+
+
+def _write_cands(path, cf, cr):
+    with open(path, "wb") as f:
+        for comp, cands in ((0, cf), (1, cr)):
+            for c in cands:
+                f.write(struct.pack("<5i", c["ref_id"], c["query_id"], c["ref_pos"], c["query_pos"], comp))
+
+
+def _lines(tmp_path, pattern):
+    import glob
+    got = []
+    for p in sorted(glob.glob(str(tmp_path / pattern))):
+        got += open(p).read().splitlines()
+    return got
+
+
+@pytest.mark.parametrize("with_n", [False, True])
+def test_recoded_read_sets_through_gact_batch(tmp_path, with_n):
+    """The reference's -DGPU build hands GACT_Batch read sets recoded in place to A0 C1 T2 G3, anything else
+    left as it is (darwin.cpp:314-398).  Same lines as the ASCII run, with and without N / lower case left in."""
+    import numpy as np
+    from gact_amd import synth
+    rs = synth.simulate_reads(30000, n_reads=20, seed=171, mean_len=5000, sd_len=1200, min_len=800, max_len=9000)
+    if with_n:
+        rng = np.random.default_rng(9)
+        for r in rs.reads[::3]:
+            r[rng.integers(0, len(r), 40)] = ord("N")
+        rs.reads[1][100:140] = np.frombuffer(rs.reads[1][100:140].tobytes().lower(), dtype=np.uint8)
+    cf, cr = synth.synth_candidates(rs, seed=172, min_overlap=300)
+    rs.write_fasta(str(tmp_path / "reads.fasta"))
+    (tmp_path / "params.cfg").write_text(CFG_GACT)
+    _write_cands(tmp_path / "cands.bin", cf, cr)
+    outs = []
+    for extra in ([], ["--recode"]):
+        out = subprocess.run([_driver(), "reads.fasta", "reads.fasta", "2", "--candidates", "cands.bin"] + extra,
+                             capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert ("Time converting bases" in out.stdout) == bool(extra)
+        for label in ("Time GACT calling", "Time elapsed (loading reads)",
+                      "Time elapsed (seed table querying + aligning)"):       # darwin.cpp:441,574,639
+            assert label in out.stdout
+        outs.append(sorted(_lines(tmp_path, "darwin.[0-9].out")))
+    assert outs[0] == outs[1] and len(outs[0]) > 40
+
+
+def test_sharded_driver_union_equals_single_run(tmp_path):
+    """darwin_hip --shard R/W --device 0: two ranks' files together are the single-process output"""
+    from gact_amd import synth
+    rs = synth.simulate_reads(30000, n_reads=20, seed=271, mean_len=5000, sd_len=1200, min_len=800, max_len=9000)
+    cf, cr = synth.synth_candidates(rs, seed=272, min_overlap=300)
+    rs.write_fasta(str(tmp_path / "reads.fasta"))
+    (tmp_path / "params.cfg").write_text(CFG_GACT)
+    _write_cands(tmp_path / "cands.bin", cf, cr)
+    base = [_driver(), "reads.fasta", "reads.fasta", "2", "--candidates", "cands.bin", "--device", "0"]
+    out = subprocess.run(base, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    single = sorted(_lines(tmp_path, "darwin.[0-9].out"))
+    for r in range(2):
+        out = subprocess.run(base + ["--shard", "%d/2" % r], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+    sharded = sorted(_lines(tmp_path, "darwin.[01].[0-9].out"))
+    assert sharded == single and len(single) > 40

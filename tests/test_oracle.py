@@ -65,6 +65,23 @@ def test_oracle_equals_reference_tiles(oracle, reflib):
         assert oracle.align_with_bt(a, b, sc, rev, first, 200) == reflib.align_with_bt(a, b, sc, rev, first, 200)
 
 
+def test_oracle_equals_reference_start_positions(oracle, reflib):
+    """(ref_pos, query_pos) inside, on the border of and beyond the tile (align.cpp:179-181,186; the matrix is
+    zero-initialised, :85): pos_score and the traceback start follow the reference"""
+    import random
+    rng = random.Random(1)
+    n = 0
+    for a, q, rev, first in random_tiles(7, 40):
+        if not len(a) or not len(q):
+            continue
+        for _ in range(5):
+            rp, qp = rng.randint(0, len(a) + 2), rng.randint(0, len(q) + 2)
+            assert oracle.align_with_bt(a, q, (1, -1, -1, -1), rev, first, 200, ref_pos=rp, query_pos=qp) == \
+                reflib.align_with_bt(a, q, (1, -1, -1, -1), rev, first, 200, ref_pos=rp, query_pos=qp)
+            n += 1
+    assert n > 100
+
+
 def test_oracle_equals_reference_chains(oracle, reflib):
     from gact_amd import synth
     rs = synth.simulate_reads(8000, n_reads=6, seed=91, mean_len=2500, sd_len=500, min_len=800, max_len=4000)

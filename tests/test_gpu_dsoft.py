@@ -112,6 +112,9 @@ def test_dsoft_device_equals_host_restatement(tmp_path, cfg):
     longish = [k for k, r in enumerate(reads) if len(r) > 2000]
     reads[longish[0]][100:700] = ord("A")             # one minimizer value for 600 positions
     reads[longish[1]][:40] = ord("N")
+    # a soft-masked stretch: NtToTwoBit decodes lower case like upper case (ntcoding.cpp:57-70)
+    reads[longish[2]][300:1500] = np.frombuffer(reads[longish[2]][300:1500].tobytes().lower(), dtype=np.uint8)
+    reads[longish[3]][:] = np.frombuffer(reads[longish[3]].tobytes().lower(), dtype=np.uint8)
     reads.append(np.frombuffer(b"ACGTACGTAC", dtype=np.uint8))                 # shorter than k + w
     reads.append(np.frombuffer(b"ACGTTGCAAGGCTTAACGGATCCA", dtype=np.uint8))
     reads.append(np.full(3000, ord("T"), dtype=np.uint8))

@@ -105,6 +105,27 @@ def build_driver(force=False, verbose=False):
     return DRIVER_PATH
 
 
+ASAN_DRIVER_PATH = DRIVER_PATH + "_asan"
+
+
+def build_driver_asan(force=False, verbose=False):
+    """the same host sources under AddressSanitizer + UndefinedBehaviorSanitizer (sanitizers run on
+    the CPU build only; the CPU suite drives it through --dsoft-only, which never touches the GPU)"""
+    build(verbose=verbose)
+    if not force and os.path.exists(ASAN_DRIVER_PATH):
+        newest = max(os.path.getmtime(s) for s in DRIVER_SOURCES + [LIB_PATH])
+        if os.path.getmtime(ASAN_DRIVER_PATH) >= newest:
+            return ASAN_DRIVER_PATH
+    cmd = ["g++", "-O1", "-g", "-std=c++14", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_PKG, "host"),
+           "-o", ASAN_DRIVER_PATH, DRIVER_SOURCES[0], DRIVER_SOURCES[1], DRIVER_SOURCES[2],
+           "-L" + _PKG, "-lgact_hip", "-Wl,-rpath," + _PKG]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return ASAN_DRIVER_PATH
+
+
 def driver_path():
     """the built driver; compiled here only if it does not exist yet (never re-built behind the back of
     concurrently running ranks -- __graft_entry__.build() is what refreshes stale binaries)"""

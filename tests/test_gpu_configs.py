@@ -1,0 +1,143 @@
+"""GPU parity at BASELINE.json's full sizes, every workload built exactly as bench.py builds it
+(synthetic reads of the config's shape, candidates from the D-SOFT filter at the reference's parameters):
+
+  config 2  ecoli10x    all 65,766 candidates against the oracle, every record field
+  config 3  pacbio50mb  every 33rd candidate (> 10,000, SURVEY 8d's gate) against the oracle, and the
+                        size-independent properties on the full list of 333,772
+  config 5  ont         all 14,501 candidates (chains of 200-500 sequential tiles, gact.cpp:82-195) against the
+                        oracle; the engine must pick the wide layout by itself
+
+The oracle side runs on the host cores of the GPU box (oracle.gact_many, contiguous candidate ranges);
+about five minutes for the three workloads together.
+"""
+import os
+import time
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles",
+          "cells")
+
+
+def _threads():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return n
+
+
+class Loaded:
+    """one workload resident on the device, run once"""
+
+    def __init__(self, name):
+        from gact_amd import engine, workload
+        t = time.time()
+        self.blk = workload.make_block(name, candidates="dsoft")
+        self.cat, self.offs = self.blk.rs.concat()
+        self.rcat, self.roffs = self.blk.rs.concat(rc=True)
+        self.eng = engine.Engine()
+        self.eng.upload(engine.SET_REF, self.cat, self.offs)
+        self.eng.upload(engine.SET_QUERY, self.cat, self.offs)
+        self.eng.upload(engine.SET_QUERY_RC, self.rcat, self.roffs)
+        self.nf, self.nr = len(self.blk.cf), len(self.blk.cr)
+        self.cands = np.concatenate([self.blk.cf, self.blk.cr])
+        self.eng.candidates_upload(self.cands)
+        self.eng.candidates_run_mixed(self.nf + self.nr, rc_from=self.nf)
+        self.rec = self.eng.candidates_fetch(self.nf + self.nr).copy()
+        self.stats = self.eng.last_run_stats()
+        print("%s: %d reads, %d + %d candidates, %d tiles, %.3e cells, layout %s, main launch %.1f ms (%.0f s to build)" % (
+            name, len(self.blk.rs.reads), self.nf, self.nr, int(self.rec["n_tiles"].sum()), float(self.rec["cells"].sum()),
+            self.stats["layout"], self.stats["main_ms"], time.time() - t))
+
+    def oracle_check(self, oracle, stride=1):
+        """candidates [::stride] of both strands through the oracle, every field compared"""
+        n = 0
+        for comp, sl, qcat, qoffs in ((False, slice(0, self.nf), self.cat, self.offs),
+                                      (True, slice(self.nf, self.nf + self.nr), self.rcat, self.roffs)):
+            cands, got = self.cands[sl][::stride], self.rec[sl][::stride]
+            want, _ = oracle.gact_many(self.cat, self.offs, qcat, qoffs, cands, complement=comp, same_file=True,
+                                       n_threads=_threads())
+            for f in FIELDS:
+                if not np.array_equal(got[f], want[f]):
+                    k = int(np.flatnonzero(got[f] != want[f])[0])
+                    raise AssertionError("%s differs at %s-strand candidate %d: hip %s, oracle %s" %
+                                         (f, "rc" if comp else "fwd", k * stride, got[k], want[k]))
+            n += len(cands)
+        return n
+
+    def close(self):
+        self.eng.close()
+
+
+def _extents_ok(w):
+    rec, rl = w.rec, np.array([len(r) for r in w.blk.rs.reads])
+    assert (rec["n_tiles"] >= 1).all() and (rec["cells"] <= rec["n_tiles"].astype(np.int64) * 320 * 320).all()
+    assert (rec["ab"] >= 0).all() and (rec["ab"] <= rec["ae"]).all() and (rec["ae"] <= rl[rec["ref_id"]]).all()
+    assert (rec["bb"] >= 0).all() and (rec["bb"] <= rec["be"]).all() and (rec["be"] <= rl[rec["query_id"]]).all()
+    assert np.array_equal(rec["comp"], (np.arange(len(rec)) >= w.nf).astype(np.int32))
+
+
+def test_config2_ecoli10x_every_candidate(oracle):
+    w = Loaded("ecoli10x")
+    try:
+        assert w.nf + w.nr == 65766 and w.stats["layout"] == "packed16-split"
+        _extents_ok(w)
+        assert w.oracle_check(oracle) == 65766
+    finally:
+        w.close()
+
+
+def test_config5_ont_every_candidate(oracle):
+    """fewer chains than resident tile slots, each up to ~500 tiles long: the latency-bound regime"""
+    w = Loaded("ont")
+    try:
+        assert w.nf + w.nr == 14501
+        assert w.stats["layout"] == "packed16-wide"          # chosen by the engine, no environment switch
+        assert w.rec["n_tiles"].max() > 400 and w.rec["n_tiles"].mean() > 150
+        _extents_ok(w)
+        assert w.oracle_check(oracle) == 14501
+    finally:
+        w.close()
+
+
+def test_config3_pacbio50mb(oracle):
+    from gact_amd import dist as gdist
+    w = Loaded("pacbio50mb")
+    try:
+        n = w.nf + w.nr
+        assert n == 333772 and w.stats["layout"] == "packed16-split"
+        _extents_ok(w)
+        assert w.rec["cells"].sum() > 1.0e12 and w.rec["emitted"].mean() > 0.5
+        # (1) the oracle on a strided sample of more than 10,000 candidates of both strands
+        assert w.oracle_check(oracle, stride=33) > 10000
+        # (2) idempotence: the persistent scheduling (atomic queues, priorities) does not leak into the records
+        w.eng.candidates_run_mixed(n, rc_from=w.nf)
+        again = w.eng.candidates_fetch(n)
+        assert zlib.crc32(again.tobytes()) == zlib.crc32(w.rec.tobytes())
+        # (3) shard invariance: the list dealt round-robin over 4 ranks and re-interleaved equals the single run
+        #     (what the 8-GPU configuration relies on); every rank here is this one GPU
+        world = 4
+        parts_f, parts_r = [], []
+        for r in range(world):
+            cf, cr = gdist.deal(w.blk.cf, r, world), gdist.deal(w.blk.cr, r, world)
+            w.eng.candidates_upload(np.concatenate([cf, cr]))
+            w.eng.candidates_run_mixed(len(cf) + len(cr), rc_from=len(cf))
+            rec = w.eng.candidates_fetch(len(cf) + len(cr))
+            parts_f.append(rec[:len(cf)].copy()); parts_r.append(rec[len(cf):].copy())
+        assert gdist.undeal(parts_f, w.nf).tobytes() == w.rec[:w.nf].tobytes()
+        assert gdist.undeal(parts_r, w.nr).tobytes() == w.rec[w.nf:].tobytes()
+        # (4) order invariance on a permuted slice of the forward strand
+        rng = np.random.default_rng(5)
+        pick = rng.permutation(w.nf)[:20000]
+        got = w.eng.extend(w.blk.cf[pick], complement=False)
+        assert got.tobytes() == w.rec[:w.nf][pick].tobytes()
+    finally:
+        w.close()

@@ -106,7 +106,7 @@ def main():
     # ---- workload: one genome block per rank, read sets replicated everywhere
     t_gen = time.time()
     blk = workload.make_block(args.workload, block=rank, candidates=args.candidates)
-    blocks = gdist.exchange_blocks(dist, (blk.rs.reads, blk.cf, blk.cr), world)
+    blocks = gdist.exchange_blocks(dist, (blk.rs.reads, blk.cf, blk.cr), world, torch=torch, device="cuda" if use_dist else "cpu")
     reads, cf_all, cr_all = gdist.merge_blocks(blocks)
     my_cf = gdist.deal(cf_all, rank, world)
     my_cr = gdist.deal(cr_all, rank, world)
@@ -137,26 +137,39 @@ def main():
 
     rec_buf = np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE)      # the job's output buffer, owned by the caller
 
+    gather = None
+    if use_dist:
+        # the one collective of the path: gather of fixed-size overlap records to rank 0, straight from
+        # the engine's device-resident record array (no host round trip in front of RCCL)
+        gather = gdist.RecordGather(torch, dist, nf + nr, engine.OVERLAP_DTYPE.itemsize, rank, world, "cuda")
+        dev_rec = gdist.DeviceRecords(eng.device_overlaps_ptr(0), nf + nr, engine.OVERLAP_DTYPE.itemsize)
+
     def step(record_ms=False):
         eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=0)
-        rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
-        rf, rr = rec[:nf], rec[nf:]
-        if record_ms:
-            kernel_ms.append(eng.last_run_stats(0))
         gathered = None
         if use_dist:
-            # the one collective of the path: gather of fixed-size overlap records
-            gathered = gdist.gather_records(torch, dist, rec, rank, world, "cuda")
-        return rf, rr, gathered
+            eng.sync(0)                                  # the engine's own stream: records complete in HBM
+            parts = gather(dev_rec)
+            if rank == 0:
+                gathered = gather.to_host(parts, engine.OVERLAP_DTYPE)      # the job's output, on the host
+            rec = gathered[0] if rank == 0 else None
+        else:
+            rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
+        if record_ms:
+            kernel_ms.append(eng.last_run_stats(0))
+        return rec, gathered
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rf, rr, gathered = step(record_ms=True)
+        rec, gathered = step(record_ms=True)
     barrier()
     dt = time.perf_counter() - t0
+    if rec is None:                                      # ranks other than 0 only need their records for the cell count
+        rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
+    rf, rr = rec[:nf], rec[nf:]
 
     my_cells = int(rf["cells"].sum() + rr["cells"].sum())
     my_tiles = int(rf["n_tiles"].sum() + rr["n_tiles"].sum())

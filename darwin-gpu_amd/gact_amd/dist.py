@@ -37,29 +37,94 @@ def merge_blocks(blocks):
     return reads, np.concatenate(cf_all), np.concatenate(cr_all)
 
 
-def exchange_blocks(dist, block, world):
-    """every rank simulated one block; afterwards every rank holds all of them"""
+def _pack_block(block):
+    """(reads, cands_fwd, cands_rc) -> one flat uint8 buffer + its four section sizes"""
+    reads, cf, cr = block
+    offs = np.zeros(len(reads) + 1, dtype=np.int64)
+    if len(reads):
+        offs[1:] = np.cumsum([len(r) for r in reads])
+    parts = [np.concatenate(reads).astype(np.uint8) if len(reads) else np.zeros(0, np.uint8),
+             offs.view(np.uint8), np.ascontiguousarray(cf).view(np.uint8).reshape(-1),
+             np.ascontiguousarray(cr).view(np.uint8).reshape(-1)]
+    return np.concatenate(parts), np.array([len(x) for x in parts], dtype=np.int64)
+
+
+def _unpack_block(buf, sizes, cand_dtype):
+    a, b, c, d = (int(x) for x in sizes)
+    cat = buf[:a]
+    offs = buf[a:a + b].copy().view(np.int64)
+    cf = buf[a + b:a + b + c].copy().view(cand_dtype)
+    cr = buf[a + b + c:a + b + c + d].copy().view(cand_dtype)
+    reads = [np.ascontiguousarray(cat[offs[k]:offs[k + 1]]) for k in range(len(offs) - 1)]
+    return reads, cf, cr
+
+
+def exchange_blocks(dist, block, world, torch=None, device="cpu"):
+    """every rank simulated one block; afterwards every rank holds all of them.  Flat byte tensors through two
+    all_gathers (section sizes, then the padded payloads) -- nothing is pickled."""
     if world == 1:
         return [block]
-    gathered = [None] * world
-    dist.all_gather_object(gathered, block)
-    return gathered
+    if torch is None:
+        import torch
+    payload, sizes = _pack_block(block)
+    all_sizes = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(all_sizes, torch.from_numpy(sizes).to(device))
+    all_sizes = [t.cpu().numpy() for t in all_sizes]
+    mx = max(int(t.sum()) for t in all_sizes)
+    mine = torch.zeros(mx, dtype=torch.uint8, device=device)
+    mine[:len(payload)] = torch.from_numpy(payload).to(device)
+    outs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(outs, mine)
+    cand_dtype = np.asarray(block[1]).dtype
+    return [_unpack_block(o.cpu().numpy(), sz, cand_dtype) for o, sz in zip(outs, all_sizes)]
+
+
+class DeviceRecords:
+    """The engine's device-resident overlap records (gact_hip_device_overlaps) as something torch can wrap without a
+    copy: the CUDA array interface, which torch.as_tensor honours on ROCm as well."""
+
+    def __init__(self, ptr, n, itemsize):
+        self.__cuda_array_interface__ = {"shape": (int(n), int(itemsize)), "typestr": "|u1", "data": (int(ptr), True),
+                                         "version": 2, "strides": None}
+
+
+class RecordGather:
+    """The one collective of the path: rank 0 receives every rank's overlap records.  The record counts
+    are fixed once the candidates are dealt, so they are exchanged once; every step after that is one padded
+    `gather` (RCCL over xGMI under the nccl backend, each peer's 32-56 B x count on its own link into rank 0)."""
+
+    def __init__(self, torch, dist, n_mine, itemsize, rank, world, device):
+        self.torch, self.dist, self.rank, self.world, self.device = torch, dist, rank, world, device
+        self.itemsize, self.n_mine = itemsize, n_mine
+        counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([n_mine], dtype=torch.int64, device=device))
+        self.counts = [int(c.item()) for c in counts]
+        mx = max(max(self.counts), 1)
+        self.buf = torch.zeros((mx, itemsize), dtype=torch.uint8, device=device)
+        self.outs = [torch.empty_like(self.buf) for _ in range(world)] if rank == 0 else None
+
+    def __call__(self, records):
+        """records: numpy structured array (host), or DeviceRecords (stays on the device: no host round trip in
+        front of the collective).  Returns the per-rank record tensors on rank 0 (still on `device`), else None."""
+        torch = self.torch
+        if isinstance(records, DeviceRecords):
+            src = torch.as_tensor(records, device=self.device)
+        else:
+            src = torch.from_numpy(np.ascontiguousarray(records).view(np.uint8).reshape(-1, self.itemsize)).to(self.device)
+        if self.n_mine:
+            self.buf[:self.n_mine].copy_(src[:self.n_mine])
+        self.dist.gather(self.buf, self.outs, dst=0)
+        if self.rank != 0:
+            return None
+        return [o[:n] for o, n in zip(self.outs, self.counts)]
+
+    def to_host(self, parts, dtype):
+        return [p.cpu().numpy().reshape(-1).view(dtype) for p in parts]
 
 
 def gather_records(torch, dist, records, rank, world, device):
-    """The one collective of the path: rank 0 receives every rank's overlap records.
-    records: structured numpy array.  Returns list of arrays on rank 0, else None."""
-    item = records.dtype.itemsize
-    mine = np.ascontiguousarray(records).view(np.uint8).reshape(-1, item)
-    counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([mine.shape[0]], dtype=torch.int64, device=device))
-    counts = [int(c.item()) for c in counts]
-    mx = max(max(counts), 1)
-    buf = torch.zeros((mx, item), dtype=torch.uint8, device=device)
-    if mine.shape[0]:
-        buf[:mine.shape[0]] = torch.from_numpy(mine.copy()).to(device)
-    outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, outs, dst=0)
-    if rank != 0:
-        return None
-    return [o[:n].cpu().numpy().reshape(-1).view(records.dtype) for o, n in zip(outs, counts)]
+    """one-shot form of RecordGather for host-side records; returns list of arrays on rank 0, else None"""
+    records = np.ascontiguousarray(records)
+    g = RecordGather(torch, dist, len(records), records.dtype.itemsize, rank, world, device)
+    parts = g(records)
+    return None if parts is None else g.to_host(parts, records.dtype)

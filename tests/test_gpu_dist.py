@@ -1,0 +1,85 @@
+"""GPU: the N>1 plumbing of bench.py on the one GPU a test box has -- torch (its bundled HIP runtime) and
+libgact_hip.so in one fresh process, the nccl (= RCCL) process group, the record gather straight from the
+engine's device memory.  The 8-GPU run itself is the driver's; the same code at world sizes 2 and 3 runs on
+CPU under gloo (tests/test_dist_gloo.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _env():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_bench_force_dist_as_a_child_process():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", "ecoli10x_small",
+                          "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"], capture_output=True, text=True,
+                         cwd=ROOT, env=_env(), timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0
+    assert res["config"]["gathered_records"] == res["config"]["candidates"] > 2000
+    assert res["parity"]["bit_exact"] is True and res["parity"]["checked_candidates"] > 100
+
+
+SCRIPT = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import torch                      # first: one HIP runtime for torch and the engine
+import torch.distributed as dist
+import numpy as np
+from gact_amd import dist as gdist, engine, synth
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+rs = synth.simulate_reads(20000, n_reads=12, seed=5, mean_len=4000, sd_len=800, min_len=800, max_len=7000)
+cf, cr = synth.synth_candidates(rs, seed=6, min_overlap=300)
+blocks = gdist.exchange_blocks(dist, (rs.reads, cf, cr), 1)
+assert len(blocks) == 1
+# the tensor form of the exchange (what ranks > 1 use), looped back through the nccl group
+payload, sizes = gdist._pack_block((rs.reads, cf, cr))
+t = torch.from_numpy(payload).cuda(); outs = [torch.empty_like(t)]
+dist.all_gather(outs, t)
+reads2, cf2, cr2 = gdist._unpack_block(outs[0].cpu().numpy(), sizes, cf.dtype)
+assert all(np.array_equal(a, b) for a, b in zip(reads2, rs.reads)) and cf2.tobytes() == cf.tobytes() and cr2.tobytes() == cr.tobytes()
+eng = engine.Engine()
+cat, offs = rs.concat(); rcat, roffs = rs.concat(rc=True)
+eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+n = len(cf) + len(cr)
+eng.candidates_upload(np.concatenate([cf, cr]))
+g = gdist.RecordGather(torch, dist, n, engine.OVERLAP_DTYPE.itemsize, 0, 1, "cuda")
+dev = gdist.DeviceRecords(eng.device_overlaps_ptr(0), n, engine.OVERLAP_DTYPE.itemsize)
+for _ in range(3):
+    eng.candidates_run_mixed(n, rc_from=len(cf)); eng.sync(0)
+    got = g.to_host(g(dev), engine.OVERLAP_DTYPE)[0]
+    want = eng.candidates_fetch(n)
+    assert got.tobytes() == want.tobytes() and want["n_tiles"].sum() > n
+host = gdist.gather_records(torch, dist, want, 0, 1, "cuda")[0]
+assert host.tobytes() == want.tobytes()
+eng.close()
+dist.destroy_process_group()
+print("GATHER_OK", n)
+"""
+
+
+def test_device_resident_gather_equals_host_fetch():
+    code = SCRIPT % (os.path.join(ROOT, "darwin-gpu_amd"), os.path.join(ROOT, "oracle"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=_env(), timeout=600)
+    assert out.returncode == 0 and "GATHER_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

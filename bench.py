@@ -197,7 +197,10 @@ def main():
         main_kernel = {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
                        "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>",
                        "packed16-wide": "extend_p16_kernel<WideLayout>"}[kernel_ms[-1]["layout"]]
-        if kernel_ms[-1]["tagged_pointers"]:           # pointer phase on tagged scores: the layouts' TAG variants
+        if kernel_ms[-1].get("linear_gap"):            # linear gap scoring: the drifted pass (gact_lin.hpp)
+            main_kernel = {"extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayoutLin<7,13>>",
+                           "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutLin>"}[main_kernel]
+        elif kernel_ms[-1]["tagged_pointers"]:         # pointer phase on tagged scores: the layouts' TAG variants
             main_kernel = {"extend_p16_kernel<UniformLayout<20>>": "extend_p16_kernel<UniformLayout<20,16,true>>",
                            "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
                            "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutTagged>"}[main_kernel]

@@ -182,11 +182,18 @@ struct ScoreWalk {
 // rrow/qrow point at the LDS byte of DP row 1 / column 1; rstride is the ref stream's
 // byte stride.  (l0, c0, k0) = lane, column-in-lane and stored step of the start cell
 // (R, Q) in the pass's layout; CW columns per lane, QN column quads stored per lane.
+//
+// FMT 3 (linear-gap pass, gact_lin.hpp): the pointer word does not say ZERO -- MATCH and ZERO share a code,
+// because H == 0 is the one case the tagged max cannot tell from M == H.  The walker knows it anyway: it
+// carries the score of the cell it stands on, v (H of the start cell comes from the pass: v0), and every move
+// takes the move's own score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE
+// step the gap score (open == extend here); after a diagonal move v is H of the new cell, and ZERO means v == 0
+// (align.cpp:166-168: M <= 0, I <= 0 and D <= 0, i.e. H == 0).
 template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
-                                           int &query_steps, int &nst)
+                                           int &query_steps, int &nst, int v0 = 0)
 {
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     const bool left = phase == 0;
@@ -216,7 +223,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
-        } else if (FMT == 2) {                                   // taken as it is: the walk runs on this numbering
+        } else if (FMT == 2 || FMT == 3) {                       // taken as it is: the walk runs on this numbering
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
@@ -228,14 +235,16 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         }
     };
 
+    int v = v0;                                                 // FMT 3: H of the current cell
     if (R >= 1 && Q >= 1 && early > 0) {
         refill(l0, c0, k0);
         fetch(l0, c0, k0, cur, fl);
+        if (FMT == 3 && v == 0) cur = 0;
     }
     // state numbering of the walk: FMT 0 / 1 words are turned into the packed kernel's op codes (1 MATCH 2 INSERT
     // 3 DELETE, flag set = the gap goes on); FMT 2 words carry align.h:23 numbering (3 MATCH 2 INSERT 1 DELETE) and
     // flags that say the opposite (set = the gap was opened here), and the walk uses them as they are
-    constexpr uint32_t kM = FMT == 2 ? 3u : 1u, kI = 2u, kD = FMT == 2 ? 1u : 3u;
+    constexpr uint32_t kM = FMT >= 2 ? 3u : 1u, kI = 2u, kD = FMT >= 2 ? 1u : 3u;
     if (left && !wk.have_left && cur != 0) { wk.have_left = 1; wk.left_first_gap = cur != kM; }
     // conditions live as lane masks on the scalar unit; a counter takes one as the carry of a single VALU op
     const uint64_t left_m = lanes(left);
@@ -249,10 +258,16 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         n_m = add_lane_bit(n_m, ~g);
         n_eq = add_lane_bit(n_eq, ~g & eq);
         gprev = (gprev & ~lanes(true)) | g;                       // walkers that have stopped keep their last column
+        if (FMT == 3) {
+            const int sub = ((eq >> (threadIdx.x & 63)) & 1) ? kp.match : kp.mismatch;
+            v -= (cur == kM) ? sub : kp.ext;
+        }
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
         nis = sub_lane_bit(nis, lanes(cur != kD));
         njs = sub_lane_bit(njs, lanes(cur != kI));
-        const uint32_t forced = FMT == 2 ? ((fl & cur) ? kM : cur) : ((fl & (4u - cur)) ? cur : kM);
+        // FMT 3 flags: bit 0 set = the insertion goes on, bit 1 set = the deletion goes on
+        const uint32_t forced = FMT == 3 ? ((fl & (cur ^ 3u)) ? cur : kM)
+                              : FMT == 2 ? ((fl & cur) ? kM : cur) : ((fl & (4u - cur)) ? cur : kM);
         // (a walker that is about to stop may have left the tile: keep its addresses inside the stored window)
         const int p = imax(p0 + njs, 0);
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
@@ -261,6 +276,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         if ((it & 7) == 7) refill(l, c, k);
         uint32_t code;
         fetch(l, c, k, code, fl);
+        if (FMT == 3) code = (v == 0) ? 0u : code;               // only looked at after a diagonal move
         const uint32_t nxt = cur == kM ? code : forced;
         cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
     }

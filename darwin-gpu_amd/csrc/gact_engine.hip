@@ -21,6 +21,7 @@
 #include "gact_kernels.hpp"
 #include "gact_p16.hpp"
 #include "gact_p16s.hpp"
+#include "gact_lin.hpp"
 #include "dsoft_device.hpp"
 
 namespace {
@@ -100,7 +101,7 @@ template <class T> struct DevBuf {
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
-    bool timed = false, two_phase = false, wide = false;
+    bool timed = false, two_phase = false, wide = false, lin = false;
     DevBuf<gact_tile> tiles;
     DevBuf<gact_tile_result> results;
     DevBuf<uint8_t> states;
@@ -167,6 +168,7 @@ struct gact_hip_engine {
     bool p16 = false;           // scoring fits the packed-int16 main kernel
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
     bool tagged = false;        // the packed main launch runs its pointer phase on tagged scores (any layout)
+    bool lin = false;           // linear gaps (open == extend == mismatch): the drifted pass of gact_lin.hpp on 2-bit sets
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
@@ -317,7 +319,8 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
     if (e->seed16) {
         const int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
-        auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
+        auto k16 = raw ? gact::seed_p16_kernel<C, true> : (e->lin && C == 20) ? gact::seed_p16_kernel<C, false, true>
+                                                                              : gact::seed_p16_kernel<C, false>;
         hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
                            kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
                            same_file, sl.overlaps.p, queues(sl), sl.d_ws);
@@ -336,7 +339,10 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         sl.wide = C == 20 && e->wide >= 0 && (e->wide > 0 || n <= narrow_slots);
         using gact::extend_p16_kernel;
         const bool tg = e->tagged;
-        auto km = sl.wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
+        sl.lin = e->lin && !raw && (sl.wide || e->split);
+        auto km = sl.lin ? (sl.wide ? extend_p16_kernel<gact::WideLayoutLin, false>
+                                    : extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>)
+                : sl.wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
                                 : (raw ? extend_p16_kernel<gact::WideLayout, true> : extend_p16_kernel<gact::WideLayout, false>))
                 : e->split ? (tg ? (raw ? extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
                                         : extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>)
@@ -361,9 +367,11 @@ template <int C> int occupancy_blocks(int *out)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_kernel<C>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::align_tiles_kernel<C>, gact::kBlockThreads, 0));
     int m = std::min(a, b);
-    for (int v = 0; v < 12; v++) {
+    for (int v = 0; v < 14; v++) {
         int c = m;
-        auto k = v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
+        auto k = v == 12 ? gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>
+               : v == 13 ? gact::extend_p16_kernel<gact::WideLayoutLin, false>
+               : v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
                : v == 1 ? gact::extend_p16_kernel<gact::UniformLayout<C>, false>
                : v == 2 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
                : v == 3 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, false>
@@ -387,7 +395,9 @@ template <int C> int seed_occupancy_blocks(int *out)
     int a = 0, b = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::seed_p16_kernel<C, true>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::seed_p16_kernel<C, false>, gact::kBlockThreads, 0));
-    *out = std::max(1, std::min(a, b));
+    int c = b;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::seed_p16_kernel<C, false, true>, gact::kBlockThreads, 0));
+    *out = std::max(1, std::min(a, std::min(b, c)));
     return 0;
 }
 
@@ -487,6 +497,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
                getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
     e->tagged = e->p16 && gact::p16_tagged_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
                 getenv("GACT_HIP_NO_TAGGED") == nullptr;
+    e->lin = e->tagged && gact::p16_lin_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
+             getenv("GACT_HIP_NO_LIN") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
@@ -502,6 +514,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->kc.open4m2 = gact::pk2(4 * p->gap_open - 2); e->kc.ext4m2 = gact::pk2(4 * p->gap_extend - 2);
     e->kc.ext4m1 = gact::pk2(4 * p->gap_extend - 1);
     e->kc.dsub4 = (uint32_t)(4 * (p->match - p->mismatch)) << 24; e->kc.floor4 = gact::pk2(-6000);
+    e->kc.next = gact::pk2(-p->gap_extend); e->kc.next4 = gact::pk2(-4 * p->gap_extend);
+    e->kc.ext4 = gact::pk2(4 * p->gap_extend);
 
     rc = (e->C == 20) ? occupancy_blocks<20>(&e->blocks_per_cu) : occupancy_blocks<32>(&e->blocks_per_cu);
     if (rc) { delete e; return rc; }
@@ -844,6 +858,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     st->packed16 = sl.two_phase ? (sl.wide ? 3 : e->split ? 2 : 1) : 0;
     st->seed_packed16 = (sl.two_phase && e->seed16) ? 1 : 0;
     st->tagged_pointers = (sl.two_phase && e->tagged) ? 1 : 0;
+    st->linear_gap = (sl.two_phase && sl.lin) ? 1 : 0;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
         HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));

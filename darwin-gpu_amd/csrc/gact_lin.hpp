@@ -1,0 +1,495 @@
+// gact_lin.hpp -- the packed-int16 chain pass for LINEAR gap scoring: gap_open == gap_extend == mismatch =: g
+// (the reference's own params.cfg: +1 / -1 / -1 / -1), 2-bit read sets.  Same cells, same results as
+// dp_pass_p16s / dp_pass_p16 -- fewer instructions per cell: 8 instead of 11 per cell pair for the scores,
+// 16 instead of 22 where pointers are made.
+//
+// 1. Row drift.  Every value of DP row i is kept as X + beta_i with beta_i = -i * g (it grows by |g| per row).
+//    In that frame the recurrence of align.cpp:134-160 loses three additions per cell:
+//      I[i][j] = max(M[i-1][j] + open, I[i-1][j] + ext)   ->  I' = max(M'_up, I'_up)            (open == ext == g)
+//      D[i][j] = max(M[i][j-1] + open, D[i][j-1] + ext)   ->  D' = max(M'_left, D'_left) + g    (same row, same frame)
+//      M[i][j] = max(H[i-1][j-1] + sub, 0)                ->  M' = max(H'_diag + (sub - g), Z)  Z = beta_i: the zero level
+//    sub - g is 0 for a mismatch (mismatch == g) and match - g otherwise: the non-negative byte the look-up word of
+//    dp_pass_p16 already holds, so no bias rides on H any more.  The drift is tied to the step, not to the
+//    tile's row number (rows in front of row 1 are virtual and behave like row 0, gact_device.hpp), so two tiles
+//    with different start delays share it.  -INF never has gap_extend added to it here.
+// 2. Tagged pointers (as dp_pass_p16s, TAG): scores times four, the two low bits say where a value came from.
+//      I'' = max(M''_up tagged 3, I''_up tagged 2)        low bits 3: the insertion was opened here, 2: it goes on
+//      D'' = max(M''_left tagged 3, D''_left tagged 1)    low bits 3: opened, 1: goes on
+//      H'' = max(M'' tagged 3, I'' re-tagged 2, D'' re-tagged 1)   the op in align.h:23 numbering
+//    flags = (I'' ^ D'') & 3 = {bit 0: insertion goes on, bit 1: deletion goes on}.
+//    H == 0 shows as op 3 like MATCH (M'' is clamped to the zero level tagged 3): ZERO is left to the walker, which
+//    carries the score of the cell it stands on (walk_chain, FMT 3).  It needs H of the start cell (R, Q): every
+//    tile of a wave is delayed so that its last row falls on the wave's last step, and the value is simply what
+//    the lane of column Q holds when the loop ends.
+#pragma once
+
+#include "gact_p16s.hpp"
+
+namespace gact {
+
+// every score, times four, plus the drift of up to kMaxSteps + lanes + lag rows must fit int16
+__host__ inline bool p16_lin_ok(int tile, int match, int mismatch, int open, int ext)
+{
+    const long long steps = (long long)tile + 4 * kGroup + 64;
+    return open == ext && mismatch == ext && ext <= 0 && match >= 0 &&
+           p16_tagged_ok(tile, match, mismatch, open, ext) &&
+           4 * ((long long)match * (tile + 2) + (long long)(-ext) * steps) + 3 <= 30000 && match - ext <= 63;
+}
+
+__device__ __forceinline__ uint32_t pk_ashr2(uint32_t a)
+{
+    uint32_t r;
+    asm("v_pk_ashrrev_i16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Split layout (see gact_p16s.hpp for the column map).  Returns, in lane 15 of every group, H[R][Q] of both tiles
+// (packed, plain scores) -- valid when every tile's last row is the wave's last step (shift = T_end - Tend).
+template <int C1, int C2>
+__device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const int gl,
+                                                      const uint16_t *__restrict__ ref16,
+                                                      const uint32_t (&qb)[C1 + C2],
+                                                      const int T_end, const int tB,
+                                                      uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB)
+{
+    constexpr int CT = C1 + C2;
+    constexpr int QD = (C2 + 3) / 4;
+    constexpr int LAG = kGroup;
+    const int g = (int)(int16_t)(kc.ext & 0xffffu);
+    // zero level of the row a lane did "before step 1": region 1 is at row t - gl, region 2 at row t - gl - LAG
+    uint32_t Z1 = pk2(gl * g), Z2 = pk2((gl + LAG) * g);
+    uint32_t G[CT], Mp[CT], I[CT];          // H, M of the previous row; I of the previous row (all drifted)
+    uint32_t accO[QD * 4], accF[QD * 4];
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+        G[c] = c < C1 ? Z1 : Z2; Mp[c] = G[c]; I[c] = kc.ninf;
+    }
+#pragma unroll
+    for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
+    uint32_t M1 = Z1, D1 = kc.ninf, H1 = Z1;            // last slot of each region as the neighbour lane will see it
+    uint32_t M2 = Z2, D2 = kc.ninf, H2 = Z2;
+    uint32_t Hdiag1 = Z1, Hdiag2 = Z2;
+    uint32_t Dl1 = kc.ninf;                             // lane 0 keeps the j = 0 border: D = -INF
+
+    auto lut = [&](uint32_t amount) { return kc.dsub >> (amount & 31u); };
+    auto lut4 = [&](uint32_t amount) { return kc.dsub4 >> (amount & 31u); };
+    uint32_t rb1 = 0, rb1b = 0, rb2 = 0, rb2b = 0;
+    {
+        const uint32_t w1 = ref16[1], w2 = ref16[1 - LAG];
+        rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
+    }
+
+    // region 1, both phases: plain drifted scores
+    // (Mp[c] turns from the previous row's M into this row's M in place: no register is copied)
+    auto r1_first = [&](uint32_t &Hd, int c) {
+        const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(rb1b, rb1, qb[c]));     // align.cpp:134-144
+        Hd = G[c];
+        I[c] = pk_max(Mp[c], I[c]);                                                  // :149-154
+        Mp[c] = pk_max(Mx, Z1);                                                      // :145-147
+    };
+    auto r1_second = [&](uint32_t &Ml, uint32_t &Dl, int c) {
+        const uint32_t D = pk_add_s(pk_max(Ml, Dl), kc.ext);                         // :151-156
+        G[c] = pk_max(pk_max(Mp[c], I[c]), D);                                       // :158-160
+        Ml = Mp[c];
+        Dl = D;
+    };
+
+    auto step = [&](const int t) {
+        const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
+        Z1 = pk_add_s(Z1, kc.next); Z2 = pk_add_s(Z2, kc.next);
+        // lane 0 of region 1 sits on the j = 0 border: M = H = 0 (the zero level), D = -INF
+        const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)M1, (int)Z1);
+        Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
+        const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
+        // lane 0 of region 2 continues lane 15's region 1 (one step ago = same row, same zero level)
+        const uint32_t Ml2 = (uint32_t)dpp_row_shr1((int)M2, dpp_row_ror1((int)M1));
+        const uint32_t Dl2 = (uint32_t)dpp_row_shr1((int)D2, dpp_row_ror1((int)D1));
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)H1));
+        uint32_t Hd = Hdiag1;
+        Hdiag1 = Hl1;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c < C1) { r1_first(Hd, c); continue; }
+            if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
+            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(rb2b, rb2, qb[c]));
+            Hd = G[c];
+            I[c] = pk_max(Mp[c], I[c]);
+            Mp[c] = pk_max(Mx, Z2);
+        }
+        uint32_t Ml = Ml1, Dl = Dl1;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c == C1) {
+                M1 = Ml; D1 = Dl; H1 = G[C1 - 1];
+                Ml = Ml2; Dl = Dl2;
+            }
+            r1_second(Ml, Dl, c);
+        }
+        M2 = Ml; D2 = Dl; H2 = G[CT - 1];
+        rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
+    };
+
+    // ---- pointer phase: region 2 on tagged scores.  Registers: G = 4H+3, Mp = 4M+3, I = 4I+2 (all drifted).
+    uint32_t Z24 = 0;
+    const uint32_t vmask = kc.nmask;
+    auto step_tagged = [&](const int t) {
+        const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
+        Z1 = pk_add_s(Z1, kc.next); Z24 = pk_add_s(Z24, kc.next4);
+        const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)M1, (int)Z1);
+        Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
+        const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
+        // lane 15's region-1 column enters region 2: scaled and tagged like a region-2 column
+        const uint32_t Ml2 = (uint32_t)dpp_row_shr1((int)M2, dpp_row_ror1((int)pk_mad4(M1, kc.c3)));
+        const uint32_t Dl2 = (uint32_t)dpp_row_shr1((int)D2, dpp_row_ror1((int)pk_mad4(D1, kc.tag1)));
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4(H1, kc.c3)));
+        uint32_t Hd = Hdiag1;
+        Hdiag1 = Hl1;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c < C1) { r1_first(Hd, c); continue; }
+            if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
+            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(rb2b, rb2, qb[c]));     // 4(H[i-1][j-1] + sub) + 3
+            Hd = G[c];
+            I[c] = pk_max(Mp[c], I[c]);                      // low bits 3: ins_open >= ins_extend (:170), 2: not
+            Mp[c] = pk_max(Mx, Z24);                                                     // 4M + 3, M >= 0
+        }
+        uint32_t Ml = Ml1, Dl = Dl1;
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+            if (c == C1) {
+                M1 = Ml; D1 = Dl; H1 = G[C1 - 1];
+                Ml = Ml2; Dl = Dl2;
+            }
+            if (c < C1) { r1_second(Ml, Dl, c); continue; }
+            const uint32_t Dp = pk_max(Ml, Dl);              // low bits 3: del_open >= del_extend (:171), 1: not
+            const uint32_t Dt = and_or(pk_add_s(Dp, kc.ext4), vmask, kc.tag1);
+            const uint32_t It = and_or(I[c], vmask, kc.tag2);
+            const uint32_t Hp = pk_max(pk_max(Mp[c], It), Dt);                           // :158-168
+            accF[c - C1] = pk_shl_add4(accF[c - C1], (I[c] ^ Dp) & kc.c3);
+            accO[c - C1] = pk_shl_add4(accO[c - C1], Hp & kc.c3);
+            G[c] = Hp | kc.c3;
+            I[c] = It;
+            Ml = Mp[c];
+            Dl = Dt;
+        }
+        M2 = Ml; D2 = Dl; H2 = G[CT - 1];
+        rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8);
+    };
+    auto enter_tagged = [&]() {
+#pragma unroll
+        for (int c = C1; c < CT; c++) {
+            G[c] = pk_mad4(G[c], kc.c3);
+            Mp[c] = pk_mad4(Mp[c], kc.c3);
+            I[c] = pk_mad4(pk_max_s(I[c], kc.floor4), kc.tag2);
+        }
+        M2 = pk_mad4(M2, kc.c3);
+        D2 = pk_mad4(pk_max_s(D2, kc.floor4), kc.tag1);
+        H2 = pk_mad4(H2, kc.c3);
+        Hdiag2 = pk_mad4(Hdiag2, kc.c3);
+        Z24 = pk_mad4(Z2, kc.c3);
+        rb2 = rb2 << 2; rb2b = rb2b << 2;               // the row already fetched: bonus times four
+    };
+
+    auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
+    auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
+
+    int t = 1;
+    for (; t < tB && t <= T_end; t++) step(t);
+    const bool tagged = t <= T_end;
+    if (tagged) enter_tagged();
+    uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
+    uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
+    // whole blocks of eight steps, each followed by its flush (an `if ((k & 7) == 7)` inside one loop is
+    // if-converted by the compiler: the 26 re-pairing v_perm of the flush would then run at every step)
+    int k = 0;
+    while (t + 7 <= T_end) {
+        for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
+        k += 8;
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            qA[q * kGroup] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
+                                        wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
+            qB[q * kGroup] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
+                                        wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
+        }
+        qA += QD * kGroup;
+        qB += QD * kGroup;
+    }
+    for (; t <= T_end; t++, k++) step_tagged(t);
+    if (k & 7) {
+        const int sh = 2 * (8 - (k & 7));
+        auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            qA[q * kGroup] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+                                        just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
+            qB[q * kGroup] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+                                        just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
+        }
+    }
+    // H of the last column at the row of the last step, drift taken off
+    return tagged ? pk_ashr2(pk_sub(H2, Z24)) : pk_sub(H2, Z2);
+}
+
+// ---------------------------------------------------------------------------
+// Uniform layout (lane gl owns columns gl*C .. gl*C + C-1; 16 or 32 lanes per tile pair), every slot tagged in the
+// pointer phase.  Two users: the wide main launch (LANES = 32, few long chains) and, with AMAX, the seed launch
+// (first tiles: pointers from step 1 on, arg-max of align.cpp:173-177 as in dp_pass_p16 -- the key 8H + (step & 7)
+// is 2 G'' - 2 Z'' + (step & 7) on the scaled, drifted scores).
+// Returns, in the lane of column Q_h, H[R][Q] of tile h in half-word h (cq[h] = that column's slot); valid when
+// every tile's last row is the wave's last step.  AMAX: the return value is not used (the walk starts at the
+// arg-max with its score).
+template <int C, int LANES, bool AMAX>
+__device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int gl,
+                                                const uint16_t *__restrict__ ref16,
+                                                const uint32_t (&qb)[C],
+                                                const int T_end, const int tB,
+                                                uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
+                                                const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb)
+{
+    constexpr int QD = (C + 3) / 4;
+    static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
+    const int g = (int)(int16_t)(kc.ext & 0xffffu);
+    uint32_t Z = pk2(gl * g);                    // zero level of the row this lane did "before step 1"
+    uint32_t G[C], Mp[C], I[C];
+    uint32_t accO[QD * 4], accF[QD * 4];
+#pragma unroll
+    for (int c = 0; c < C; c++) { G[c] = Z; Mp[c] = Z; I[c] = kc.ninf; }
+#pragma unroll
+    for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
+    uint32_t M_last = Z, D_last = kc.ninf, G_last = Z, Hdiag = Z, Dl0 = kc.ninf;
+
+    // arg-max state (see dp_pass_p16)
+    uint32_t bk[AMAX ? C : 1];
+    int lane_best[2] = {-1, -1};
+    uint32_t col_x0 = 0;
+    int t_first = 0, rows[2] = {0, 0};
+    if (AMAX) {
+#pragma unroll
+        for (int c = 0; c < C; c++) bk[c] = 0xffffffffu;
+        const int ncA = imin(imax(RQ[0][1] - gl * C, 0), C), ncB = imin(imax(RQ[1][1] - gl * C, 0), C);
+        col_x0 = ((uint32_t)(-ncA) & 0xffffu) | ((uint32_t)(-ncB) << 16);
+        t_first = gl + 1;
+        rows[0] = RQ[0][0]; rows[1] = RQ[1][0];
+    }
+
+    auto lut = [&](uint32_t amount) { return kc.dsub >> (amount & 31u); };
+    auto lut4 = [&](uint32_t amount) { return kc.dsub4 >> (amount & 31u); };
+    uint32_t lutA = 0, lutB = 0;
+    { const uint32_t w = ref16[1]; lutA = lut(w & 0xffu); lutB = lut(w >> 8); }
+
+    auto shr1 = [](uint32_t v, uint32_t old) {
+        return (uint32_t)(LANES == 32 ? dpp_shr1_32((int)v, (int)old) : dpp_row_shr1((int)v, (int)old));
+    };
+
+    auto step = [&](const int t) {
+        const uint32_t w_next = ref16[t + 1];
+        Z = pk_add_s(Z, kc.next);
+        const uint32_t Ml0 = shr1(M_last, Z);
+        Dl0 = shr1(D_last, Dl0);
+        const uint32_t Hl = shr1(G_last, Z);
+        uint32_t Hd = Hdiag;
+        Hdiag = Hl;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(lutB, lutA, qb[c]));
+            Hd = G[c];
+            I[c] = pk_max(Mp[c], I[c]);
+            Mp[c] = pk_max(Mx, Z);
+        }
+        uint32_t Ml = Ml0, Dl = Dl0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t D = pk_add_s(pk_max(Ml, Dl), kc.ext);
+            G[c] = pk_max(pk_max(Mp[c], I[c]), D);
+            Ml = Mp[c];
+            Dl = D;
+        }
+        M_last = Ml; D_last = Dl; G_last = G[C - 1];
+        lutA = lut(w_next & 0xffu); lutB = lut(w_next >> 8);
+    };
+
+    uint32_t Z4 = 0, Z8 = 0;
+    const uint32_t vmask = kc.nmask;
+    auto step_tagged = [&](const int t) {
+        const uint32_t w_next = ref16[t + 1];
+        Z4 = pk_add_s(Z4, kc.next4);
+        uint32_t key_c = 0;
+        if (AMAX) {
+            Z8 = pk_add_s(pk_add_s(Z8, kc.next4), kc.next4);
+            const uint32_t sidx = (uint32_t)(t - tB) & 7u, row0 = (uint32_t)(t - t_first);
+            const uint32_t ka = row0 < (uint32_t)rows[0] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
+            const uint32_t kb = row0 < (uint32_t)rows[1] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
+            key_c = pk_sub(ka | (kb << 16), Z8);
+        }
+        const uint32_t Ml0 = shr1(M_last, Z4);
+        Dl0 = shr1(D_last, Dl0);
+        const uint32_t Hl = shr1(G_last, Z4);
+        uint32_t Hd = Hdiag;
+        Hdiag = Hl;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(lutB, lutA, qb[c]));
+            Hd = G[c];
+            I[c] = pk_max(Mp[c], I[c]);
+            Mp[c] = pk_max(Mx, Z4);
+        }
+        uint32_t Ml = Ml0, Dl = Dl0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t Dp = pk_max(Ml, Dl);
+            const uint32_t Dt = and_or(pk_add_s(Dp, kc.ext4), vmask, kc.tag1);
+            const uint32_t It = and_or(I[c], vmask, kc.tag2);
+            const uint32_t Hp = pk_max(pk_max(Mp[c], It), Dt);
+            accF[c] = pk_shl_add4(accF[c], (I[c] ^ Dp) & kc.c3);
+            accO[c] = pk_shl_add4(accO[c], Hp & kc.c3);
+            G[c] = Hp | kc.c3;
+            if (AMAX) bk[c] = pk_max(bk[c], pk_mad_vvv(G[c], kc.tag2, key_c));      // 2 G'' + (step & 7) - 2 Z''
+            I[c] = It;
+            Ml = Mp[c];
+            Dl = Dt;
+        }
+        M_last = Ml; D_last = Dl; G_last = G[C - 1];
+        lutA = lut4(w_next & 0xffu); lutB = lut4(w_next >> 8);
+    };
+    auto enter_tagged = [&]() {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            G[c] = pk_mad4(G[c], kc.c3);
+            Mp[c] = pk_mad4(Mp[c], kc.c3);
+            I[c] = pk_mad4(pk_max_s(I[c], kc.floor4), kc.tag2);
+        }
+        M_last = pk_mad4(M_last, kc.c3);
+        D_last = pk_mad4(pk_max_s(D_last, kc.floor4), kc.tag1);
+        Dl0 = pk_mad4(pk_max_s(Dl0, kc.floor4), kc.tag1);
+        G_last = pk_mad4(G_last, kc.c3);
+        Hdiag = pk_mad4(Hdiag, kc.c3);
+        Z4 = pk_mad4(Z, kc.c3);
+        Z8 = pk_add(Z4, Z4);
+        lutA <<= 2; lutB <<= 2;
+    };
+
+    auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
+    auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
+
+    // fold the block keys of stored steps kblk..kblk+7 into lane_best (as dp_pass_p16)
+    auto fold = [&](const int kblk) {
+        uint32_t m = 0xffffffffu, rel = 0, x = col_x0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t v = pk_sign(x);
+            x = pk_add(x, kc.one);
+            const uint32_t key = pk_mad_m1(v, pk_add(bk[AMAX ? c : 0], kc.one));
+            const uint32_t keep = pk_sign(pk_sub(key, m));
+            rel = pk_mad_m1(keep, rel);
+            m = pk_max(m, key);
+            bk[AMAX ? c : 0] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int m16 = (int)(m << (16 - 16 * h)) >> 16;
+            const int col = ((int)(rel << (16 - 16 * h)) >> 16) + C;
+            const int rec = ((m16 >> 3) << 15) | ((kblk + (m16 & 7)) << 5) | col;
+            lane_best[h] = imax(lane_best[h], m16 < 0 ? -1 : rec);
+        }
+    };
+
+    int t = 1;
+    for (; t < tB && t <= T_end; t++) step(t);
+    const bool tagged = t <= T_end;
+    if (tagged) enter_tagged();
+    uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
+    uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
+    int k = 0;
+    while (t + 7 <= T_end) {                     // whole blocks of eight steps + flush (see dp_pass_lin_split)
+        for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
+        k += 8;
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            qA[q * LANES] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
+                                       wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
+            qB[q * LANES] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
+                                       wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
+        }
+        qA += QD * LANES;
+        qB += QD * LANES;
+        if (AMAX) fold(k - 8);
+    }
+    for (; t <= T_end; t++, k++) step_tagged(t);
+    if (AMAX) {
+        if (k & 7) fold(k & ~7);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int rec = lane_best[h];
+            int best = 0, bi = 0, bj = 0;                               // align.cpp:109-112
+            if (rec >= 0) {
+                best = rec >> 15;
+                bi = tB + ((rec >> 5) & 1023) - gl;
+                bj = gl * C + (rec & 31) + 1;
+            }
+#pragma unroll
+            for (int mm = 1; mm < kGroup; mm <<= 1) {
+                const int ob = __shfl_xor(best, mm, kGroup);
+                const int oi = __shfl_xor(bi, mm, kGroup);
+                const int oj = __shfl_xor(bj, mm, kGroup);
+                const bool take = (ob > best) | ((ob == best) & ((oi > bi) | ((oi == bi) & (oj > bj))));
+                best = take ? ob : best;
+                bi = take ? oi : bi;
+                bj = take ? oj : bj;
+            }
+            pb->best[h] = best; pb->bi[h] = bi; pb->bj[h] = bj;
+        }
+    }
+    if (k & 7) {
+        const int sh = 2 * (8 - (k & 7));
+        auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            qA[q * LANES] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+                                       just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
+            qB[q * LANES] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+                                       just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
+        }
+    }
+    if (AMAX) return 0;
+    // H[R][Q]: slot cq of the lane that owns column Q, at the row of the last step; drift taken off
+    uint32_t ga = G[0], gb = G[0];
+#pragma unroll
+    for (int c = 1; c < C; c++) { ga = (c == cqA) ? G[c] : ga; gb = (c == cqB) ? G[c] : gb; }
+    const uint32_t pick = __builtin_amdgcn_perm(gb, ga, 0x07060100u);           // {tile B's half of gb, tile A's half of ga}
+    return tagged ? pk_ashr2(pk_sub(pick, Z4)) : pk_sub(pick, Z);
+}
+
+// The wide main launch of linear scorings: UniformLayout<10, 32>'s column map, the pass above, FMT 3 words
+struct WideLayoutLin : UniformLayout<10, 32, true> {
+    static constexpr int kWalkFmt = 3;
+    static constexpr bool kEndAligned = true;
+    template <bool RAW>
+    __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[10], int T_end,
+                                    int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &pt)
+    {
+        static_assert(!RAW, "the linear-gap pass reads 2-bit sets");
+        return dp_pass_lin<10, 32, false>(kc, gl, ref16, qb, T_end, tB, wsA, wsB, (imax(pt.Q[0], 1) - 1) % 10,
+                                          (imax(pt.Q[1], 1) - 1) % 10, nullptr, nullptr);
+    }
+    __device__ static int fin_lane(int Q) { return (imax(Q, 1) - 1) / 10; }
+};
+
+// Layout policy for extend_p16_kernel: SplitLayout's column map, the linear-gap pass, FMT 3 pointer words
+template <int C1, int C2> struct SplitLayoutLin : SplitLayout<C1, C2, true> {
+    static constexpr int kWalkFmt = 3;
+    static constexpr bool kEndAligned = true;       // every tile's last row on the wave's last step
+    template <bool RAW>
+    __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
+                                    int T_end, int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &pt)
+    {
+        static_assert(!RAW, "the linear-gap pass reads 2-bit sets");
+        (void)pt;
+        return dp_pass_lin_split<C1, C2>(kc, gl, ref16, qb, T_end, tB, wsA, wsB);
+    }
+    // lane and half-word of pass()'s return value that hold H[R][Q] of slot h
+    __device__ static int fin_lane(int Q) { (void)Q; return kGroup - 1; }
+};
+
+}  // namespace gact

@@ -55,6 +55,10 @@ struct P16Consts {
     uint32_t ext4m1;    // 4 * gap_extend - 1: D tagged 1 -> del_extend tagged 0
     uint32_t dsub4;     // 4 * (match - mismatch) << 24
     uint32_t floor4;    // -6000: what is still -INF when the scores are scaled
+    // linear-gap pass (gact_lin.hpp): the row drift's step and the scaled gap score
+    uint32_t next;      // -gap_extend
+    uint32_t next4;     // -4 * gap_extend
+    uint32_t ext4;      // 4 * gap_extend
 };
 
 __host__ __device__ inline uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -573,6 +577,8 @@ template <int C, int LANES = kGroup, bool TAG = false> struct UniformLayout {
     static constexpr int kSlotsPerLane = C;
     static constexpr int kWalkCols = C, kWalkQuads = G::kQuads, kWalkFmt = TAG ? 2 : 1;   // for the walker
     static constexpr int kRow0 = LANES;                           // ref stream entry of (delay 0, row 1)
+    static constexpr bool kEndAligned = false;                    // tiles are delayed no more than the pointer start asks
+    __device__ static int fin_lane(int Q) { (void)Q; return 0; }
     // register budget: 32 columns per lane need a whole SIMD's file
     static constexpr int kBlocksPerCu = C <= 20 ? 3 : 1;
     __device__ static int last_step(int R, int Q) { return gact::last_step<C>(R, Q); }
@@ -582,9 +588,9 @@ template <int C, int LANES = kGroup, bool TAG = false> struct UniformLayout {
                                 const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C])
     { load_pair<C, RAW, LANES>(rs, qf, qr, pt, gl, ref8, q8, qb); }
     template <bool RAW>
-    __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C], int T_end,
-                                int tB, uint32_t *wsA, uint32_t *wsB)
-    { dp_pass_p16<C, false, RAW, LANES, TAG>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C], int T_end,
+                                    int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &)
+    { dp_pass_p16<C, false, RAW, LANES, TAG>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); return 0; }
     // start cell (R, Q) of the traceback: lane, column in lane, stored step (tB_tile = tile's own first stored step)
     __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
     { l = (Q - 1) / C; c = (Q - 1) - l * C; k = R + l - tB_tile; }
@@ -703,8 +709,9 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         const int reach0 = have[0] ? tB_h[0] + (T_end - Tend_h[0]) : 0x7fffffff;
         const int reach1 = have[1] ? tB_h[1] + (T_end - Tend_h[1]) : 0x7fffffff;
         const int tB = wave_min_groups<LANES>(imin(reach0, reach1));
-        pt.shift[0] = have[0] ? imax(0, tB - tB_h[0]) : 0;
-        pt.shift[1] = have[1] ? imax(0, tB - tB_h[1]) : 0;
+        // (a layout whose walker wants H[R][Q] from the pass delays every tile all the way: last row = last step)
+        pt.shift[0] = have[0] ? (L::kEndAligned ? T_end - Tend_h[0] : imax(0, tB - tB_h[0])) : 0;
+        pt.shift[1] = have[1] ? (L::kEndAligned ? T_end - Tend_h[1] : imax(0, tB - tB_h[1])) : 0;
 
         GACT_STAMP(t_b);
         uint32_t qb[L::kSlotsPerLane];
@@ -727,8 +734,14 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         if (rank_hi) __builtin_amdgcn_s_setprio(2);
         else if (rank_mid) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
-        L::template pass<RAW>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB);
+        const uint32_t fin = L::template pass<RAW>(kc, w.gl, ref16_lane, qb, T_end, tB, wsA, wsB, pt);
         __builtin_amdgcn_s_setprio(3);
+        // FMT 3 walkers start from H[R][Q]: held by the lane of column Q when the pass ends
+        int v0_h[kSlots] = {0, 0};
+        if (L::kWalkFmt == 3) {
+            v0_h[0] = (int)(int16_t)(__shfl(fin, L::fin_lane(pt.Q[0]), LANES) & 0xffffu);
+            v0_h[1] = (int)(int16_t)(__shfl(fin, L::fin_lane(pt.Q[1]), LANES) >> 16);
+        }
         GACT_STAMP(t_d);
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pointer stores -> L2 before the sc1 loads
@@ -752,7 +765,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
                 walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, LANES>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
-                                                           query_steps, nst);
+                                                           query_steps, nst, h ? v0_h[1] : v0_h[0]);
             }
         }
         GACT_STAMP(t_f);
@@ -788,12 +801,19 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
 #endif
 }
 
+// the linear-gap pass (gact_lin.hpp), uniform layout; LIN seed launch below
+template <int C, int LANES, bool AMAX>
+__device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int gl, const uint16_t *__restrict__ ref16,
+                                                const uint32_t (&qb)[C], const int T_end, const int tB,
+                                                uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
+                                                const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb);
+
 // ---------------------------------------------------------------------------
 // Packed seed launch: the first tile(s) of every candidate (arg-max, pointers of the
 // whole tile), two candidates per group, then the chain is handed to the main launch
 // (ChainQueues) exactly as the int32 seed launch does (extend_kernel, seed_mode).
-// Needs p16_argmax_ok on top of p16_scoring_ok.
-template <int C, bool RAW>
+// Needs p16_argmax_ok on top of p16_scoring_ok.  LIN: linear gap scoring on 2-bit sets (gact_lin.hpp).
+template <int C, bool RAW, bool LIN = false>
 __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     const gact_candidate *__restrict__ cands, int first_cand, int n, int rc_from,
@@ -865,7 +885,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
 
         P16Best pb;
         __builtin_amdgcn_s_setprio(0);
-        dp_pass_p16<C, true, RAW>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, RQ, &pb);
+        if (LIN) dp_pass_lin<C, kGroup, true>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, 0, 0, RQ, &pb);
+        else dp_pass_p16<C, true, RAW>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, RQ, &pb);
         __builtin_amdgcn_s_setprio(3);
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pointer stores -> L2 before the sc1 loads
@@ -897,9 +918,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
             if (mine) {
                 const int i0 = h ? pb.bi[1] : pb.bi[0], j0 = h ? pb.bj[1] : pb.bj[0];
                 const int l0 = (j0 - 1) / C;
-                walk_chain<C, 1, C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
-                                        i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
-                                        s.phase, kp, wk, ref_steps, query_steps, nst);
+                // (FMT 3 walkers start from the score of their cell: the arg-max)
+                walk_chain<C, LIN ? 3 : 1, C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
+                                                  i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
+                                                  s.phase, kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0]);
             }
         }
         // ---- consume; a chain whose first tile is done belongs to the main launch

@@ -354,6 +354,8 @@ template <int C1, int C2, bool TAG = false> struct SplitLayout {
     static constexpr int kLanes = kGroup;
     static constexpr int kRow0 = G::kRow0;
     static constexpr int kBlocksPerCu = 3;
+    static constexpr bool kEndAligned = false;
+    __device__ static int fin_lane(int Q) { (void)Q; return 0; }
     __device__ static int last_step(int R, int Q) { return split_last_step<C2>(R, Q); }
     __device__ static int first_pointer_step(int R, int Q, int early) { return split_first_pointer_step<C2>(R, Q, early); }
     template <bool RAW>
@@ -361,9 +363,9 @@ template <int C1, int C2, bool TAG = false> struct SplitLayout {
                                 const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C1 + C2])
     { load_pair_split<C1, C2, RAW>(rs, qf, qr, pt, gl, ref8, q8, qb); }
     template <bool RAW>
-    __device__ static void pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
-                                int T_end, int tB, uint32_t *wsA, uint32_t *wsB)
-    { dp_pass_p16s<C1, C2, RAW, TAG>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); }
+    __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
+                                    int T_end, int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &)
+    { dp_pass_p16s<C1, C2, RAW, TAG>(kc, gl, ref16, qb, T_end, tB, wsA, wsB); return 0; }
     // the start cell (R, Q) is the last column of region 2: lane 15, slot C2-1
     __device__ static void walk_start(int R, int Q, int tB_tile, int &l, int &c, int &k)
     { (void)Q; l = kGroup - 1; c = C2 - 1; k = R + (kGroup - 1) - tB_tile; }

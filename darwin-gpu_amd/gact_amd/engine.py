@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # darwin-gp
 _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp",
+           ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp", "gact_lin.hpp",
             "dsoft_device.hpp", "dsoft_engine.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
@@ -46,7 +46,7 @@ class DeviceInfo(C.Structure):
 class RunStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("seed_ms", C.c_float), ("main_ms", C.c_float),
                 ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_packed16", C.c_int32),
-                ("tagged_pointers", C.c_int32), ("seed_cells", C.c_int64)]
+                ("tagged_pointers", C.c_int32), ("linear_gap", C.c_int32), ("seed_cells", C.c_int64)]
 
 
 class DsoftParams(C.Structure):
@@ -339,7 +339,7 @@ class Engine:
         return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
                 "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split", "packed16-wide")[st.packed16],
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
-                "tagged_pointers": bool(st.tagged_pointers),
+                "tagged_pointers": bool(st.tagged_pointers), "linear_gap": bool(st.linear_gap),
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells}
 
     def measure_valu_rate(self):

@@ -253,6 +253,7 @@ typedef struct {
     int32_t handed_off;                 /* candidates the main launch continued */
     int32_t seed_packed16;              /* 1: the seed launch ran the packed-int16 arg-max kernel, 0: the int32 one */
     int32_t tagged_pointers;            /* 1: the split layout ran its pointer phase on tagged scores */
+    int32_t linear_gap;                 /* 1: the main launch ran the linear-gap pass (open == extend == mismatch) */
     int64_t seed_cells;                 /* DP cells executed by the seed launch */
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);

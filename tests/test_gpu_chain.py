@@ -38,20 +38,23 @@ def _run(rs, cf, cr, oracle, scoring=(1, -1, -1, -1), tile=320, overlap=120, thr
     return total
 
 
-@pytest.fixture(params=["packed16", "packed16-plain", "packed16-uniform", "packed16-wide", "int32-seed", "int32"],
-                autouse=True)
+@pytest.fixture(params=["packed16", "packed16-affine", "packed16-plain", "packed16-uniform", "packed16-wide",
+                        "packed16-wide-affine", "int32-seed", "int32"], autouse=True)
 def kernel_family(request, monkeypatch):
-    """every chain test runs six times: packed seed + packed main launch in its split layout (what many chains
-    get where the geometry allows it; tagged pointer scheme where the scoring allows it), the same with explicit
-    pointer comparisons, the same in the uniform layout, the same in the wide layout (32 lanes per
+    """every chain test runs eight times: packed seed + packed main launch in its split layout (what many chains
+    get where the geometry allows it; the linear-gap pass where open == extend == mismatch, else the tagged
+    pointer scheme where the scoring allows it), the same with the affine pass whatever the scoring, the same with
+    explicit pointer comparisons, the same in the uniform layout, the same in the wide layout (32 lanes per
     tile pair: what few chains get), the int32 seed launch in front of the packed main launch, and the int32
     kernel alone"""
     for var in ("GACT_HIP_FORCE_INT32", "GACT_HIP_FORCE_UNIFORM", "GACT_HIP_FORCE_INT32_SEED", "GACT_HIP_FORCE_WIDE",
-                "GACT_HIP_NO_WIDE", "GACT_HIP_NO_TAGGED"):
+                "GACT_HIP_NO_WIDE", "GACT_HIP_NO_TAGGED", "GACT_HIP_NO_LIN"):
         monkeypatch.delenv(var, raising=False)
+    if request.param in ("packed16-affine", "packed16-wide-affine"):
+        monkeypatch.setenv("GACT_HIP_NO_LIN", "1")           # tagged affine pass also for linear scorings
     if request.param == "packed16-plain":
         monkeypatch.setenv("GACT_HIP_NO_TAGGED", "1")        # split layout with explicit pointer comparisons
-    if request.param != "packed16-wide":
+    if not request.param.startswith("packed16-wide"):
         monkeypatch.setenv("GACT_HIP_NO_WIDE", "1")          # the tests' candidate lists are short
     else:
         monkeypatch.setenv("GACT_HIP_FORCE_WIDE", "1")
@@ -64,6 +67,9 @@ def kernel_family(request, monkeypatch):
     return request.param
 
 
+LIN_FAMILIES = ("packed16", "packed16-wide", "int32-seed")          # families whose main launch may take the linear-gap pass
+
+
 def test_kernel_family_is_the_one_asked_for(kernel_family):
     from gact_amd import engine, synth
     rs = synth.simulate_reads(9000, n_reads=6, seed=2, mean_len=3000, sd_len=300, min_len=1500, max_len=4000)
@@ -73,12 +79,14 @@ def test_kernel_family_is_the_one_asked_for(kernel_family):
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
     eng.extend(cf)
     st = eng.last_run_stats()
-    assert st["layout"] == {"packed16": "packed16-split", "packed16-plain": "packed16-split",
-                            "packed16-uniform": "packed16-uniform",
-                            "packed16-wide": "packed16-wide", "int32-seed": "packed16-split",
+    assert st["layout"] == {"packed16": "packed16-split", "packed16-affine": "packed16-split",
+                            "packed16-plain": "packed16-split", "packed16-uniform": "packed16-uniform",
+                            "packed16-wide": "packed16-wide", "packed16-wide-affine": "packed16-wide",
+                            "int32-seed": "packed16-split",
                             "int32": "int32"}[kernel_family]
     assert st["seed_layout"] == ("packed16" if kernel_family.startswith("packed16") else "int32")
     assert st["tagged_pointers"] == (kernel_family not in ("packed16-plain", "int32"))
+    assert st["linear_gap"] == (kernel_family in LIN_FAMILIES)        # default scoring is linear: +1 / -1 / -1 / -1
     if st["packed16"]:
         assert 0 < st["handed_off"] <= len(cf) and st["seed_cells"] > 0
     eng.close()
@@ -104,13 +112,23 @@ def test_chain_small(oracle):
     assert _run(rs, cf, cr, oracle) > 100
 
 
+# (match, mismatch, open, extend); the last four are linear (open == extend == mismatch): the drifted pass
 @pytest.mark.parametrize("scoring", [(2, -3, -5, -2), (5, -4, -10, -1), (1, -1, -2, -1), (30, -40, -70, -20),
-                                     (6, -4, 0, 0), (3, 0, -2, 0)])
-def test_chain_other_scoring(oracle, scoring):
-    from gact_amd import synth
+                                     (6, -4, 0, 0), (3, 0, -2, 0),
+                                     (2, -3, -3, -3), (5, -2, -2, -2), (1, 0, 0, 0), (3, -7, -7, -7)])
+def test_chain_other_scoring(oracle, scoring, kernel_family):
+    from gact_amd import engine, synth
     rs = synth.simulate_reads(20000, n_reads=16, seed=8, mean_len=4000, sd_len=1000, min_len=800, max_len=8000)
     cf, cr = synth.synth_candidates(rs, seed=9, min_overlap=300)
     _run(rs, cf, cr, oracle, scoring=scoring)
+    if kernel_family in LIN_FAMILIES:
+        # the engine took the linear pass exactly where the scoring is linear
+        eng = engine.Engine(scoring=scoring)
+        cat, offs = rs.concat()
+        eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
+        eng.extend(cf[:8])
+        assert eng.last_run_stats()["linear_gap"] == (scoring[1] == scoring[2] == scoring[3])
+        eng.close()
 
 
 @pytest.mark.parametrize("tile,overlap,thr", [(320, 120, 35), (128, 32, 20), (200, 100, 35), (320, 200, 60),

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SRC = r'''
 #include <cstdio>
-#include "gact_p16.hpp"
+#include "gact_lin.hpp"
 int main()
 {
     int prev = -1, ok = 1;
@@ -26,6 +26,10 @@ int main()
            gact::p16_tagged_ok(320, 30, -40, -70, -20));
     printf("tile512 %d %d\n", gact::p16_scoring_ok(512, 1, -1, -1, -1), gact::p16_tagged_ok(512, 1, -1, -1, -1));
     printf("pk2 %08x %08x\n", gact::pk2(-1), gact::pk2(3));
+    // linear-gap pass: open == extend == mismatch, and the drift must fit next to the scaled scores
+    printf("lin %d %d %d %d %d %d\n", gact::p16_lin_ok(320, 1, -1, -1, -1), gact::p16_lin_ok(320, 1, -1, -2, -1),
+           gact::p16_lin_ok(320, 2, -1, -3, -3), gact::p16_lin_ok(320, 5, -2, -2, -2), gact::p16_lin_ok(320, 3, -20, -20, -20),
+           gact::p16_lin_ok(512, 1, -1, -1, -1));
     return 0;
 }
 '''
@@ -43,3 +47,4 @@ def test_length_classes_and_kernel_predicates(tmp_path):
     assert out[3] == "mid 1 0 0"                    # packed main kernel yes; int32 seed kernel, explicit pointer comparisons
     assert out[4] == "tile512 1 1"
     assert out[5] == "pk2 ffffffff 00030003"
+    assert out[6] == "lin 1 0 0 1 0 1"

@@ -236,6 +236,8 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     };
 
     int v = v0;                                                 // FMT 3: H of the current cell
+    const int s_gap = __builtin_amdgcn_readfirstlane(kp.ext), s_dm = __builtin_amdgcn_readfirstlane(kp.mismatch - kp.ext),
+              s_de = __builtin_amdgcn_readfirstlane(kp.match - kp.mismatch);
     if (R >= 1 && Q >= 1 && early > 0) {
         refill(l0, c0, k0);
         fetch(l0, c0, k0, cur, fl);
@@ -259,8 +261,11 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         n_eq = add_lane_bit(n_eq, ~g & eq);
         gprev = (gprev & ~lanes(true)) | g;                       // walkers that have stopped keep their last column
         if (FMT == 3) {
-            const int sub = ((eq >> (threadIdx.x & 63)) & 1) ? kp.match : kp.mismatch;
-            v -= (cur == kM) ? sub : kp.ext;
+            // (differences of scalars held in registers: a select between kp's fields themselves is turned into an
+            // indexed load from the kernel argument segment, one memory round trip per step)
+            int cost = add_lane_bit_scaled(s_gap, lanes(cur == kM), s_dm);        // gap, or mismatch for a MATCH step ...
+            cost = add_lane_bit_scaled(cost, eq & lanes(cur == kM), s_de);         // ... or match
+            v -= cost;
         }
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
         nis = sub_lane_bit(nis, lanes(cur != kD));
@@ -316,12 +321,23 @@ __device__ __forceinline__ void chain_advance(ChainState &s, bool stop, const Sc
 // launch lasts as long as the chains popped last, so the classes are one tile
 // wide at the short end (measured with 16 classes of 8 tiles: queues empty at
 // 61 ms, last wave done at 73 ms) and coarser where only the order matters:
-// 0..15 tiles one class each, 16..47 in fours, 48..111 in eights, longer in one.
-constexpr int kBuckets = 32;
+// 0..15 tiles one class each, 16..47 in fours, 48..111 in eights, 112..607 in sixteens, longer in one.  (With
+// everything beyond 112 tiles in one class, the 50-100 kb reads of the ONT-shape workload -- chains of up to 500
+// tiles -- were popped in no particular order, and a 500-tile chain could start last.)
+#ifndef GACT_AB_BUCKETS32
+constexpr int kBuckets = 64;
 __host__ __device__ constexpr int length_class(int tiles)      // ascending with the length, 0 .. kBuckets-1
+{
+    return tiles < 16 ? (tiles < 0 ? 0 : tiles) : tiles < 48 ? 16 + (tiles - 16) / 4 : tiles < 112 ? 24 + (tiles - 48) / 8
+         : tiles < 608 ? 32 + (tiles - 112) / 16 : 63;
+}
+#else
+constexpr int kBuckets = 32;
+__host__ __device__ constexpr int length_class(int tiles)
 {
     return tiles < 16 ? (tiles < 0 ? 0 : tiles) : tiles < 48 ? 16 + (tiles - 16) / 4 : tiles < 112 ? 24 + (tiles - 48) / 8 : 31;
 }
+#endif
 struct ChainQueues {
     int *pop_seed;               // next candidate index for the seed launch
     int *bucket_count;           // [kBuckets] candidates handed to the main launch, bucket 0 = longest

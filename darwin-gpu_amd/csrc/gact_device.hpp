@@ -90,6 +90,13 @@ __device__ __forceinline__ int add_lane_bit(int x, uint64_t lane_mask)
     asm("s_nop 1\n\tv_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(lane_mask));
     return r;
 }
+// x + (bit(lane) ? k : 0) with a wave-uniform k
+__device__ __forceinline__ int add_lane_bit_scaled(int x, uint64_t lane_mask, int k)
+{
+    int r;
+    asm("s_nop 1\n\tv_cndmask_b32 %0, 0, %1, %2" : "=v"(r) : "v"(k), "s"(lane_mask));
+    return x + r;
+}
 __device__ __forceinline__ int sub_lane_bit(int x, uint64_t lane_mask)
 {
     int r;

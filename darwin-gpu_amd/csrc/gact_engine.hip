@@ -170,6 +170,7 @@ struct gact_hip_engine {
     bool tagged = false;        // the packed main launch runs its pointer phase on tagged scores (any layout)
     bool lin = false;           // linear gaps (open == extend == mismatch): the drifted pass of gact_lin.hpp on 2-bit sets
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
+    int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
@@ -352,7 +353,12 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                                         : extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, false>)
                                  : (raw ? extend_p16_kernel<gact::UniformLayout<C>, true>
                                         : extend_p16_kernel<gact::UniformLayout<C>, false>));
-        const int wide_blocks = std::max(1, std::min((n + 15) / 16, e->grid_blocks));      // 4 tiles per wave
+        // two waves per SIMD, not three: this launch lasts as long as its longest chain, and a wave advances a chain
+        // at one instruction per ~11 cycles with one neighbour on its SIMD, ~15 with two (8 alone, but then half the
+        // VALU idles): ONT-shape workload 150 ms -> 116 ms; one wave per SIMD: 132 ms
+        const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : 2;
+        const int wide_cap = std::min(e->grid_blocks, per_cu * e->prop.multiProcessorCount);
+        const int wide_blocks = std::max(1, std::min((n + 15) / 16, wide_cap));             // 4 tiles per wave
         hipLaunchKernelGGL(km, dim3(sl.wide ? wide_blocks : main_blocks), dim3(gact::kBlockThreads), 0, sl.stream, kp,
                            e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file, sl.overlaps.p,
                            queues(sl), sl.d_ws);
@@ -502,6 +508,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
+    if (const char *v = getenv("GACT_HIP_WIDE_BLOCKS_PER_CU")) e->wide_blocks_per_cu = atoi(v);
     e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;
     static_assert(gact::GeometrySplit<7, 13>::kWsWords <= gact::Geometry<20>::kWsWords, "workspace too small");
     e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);

@@ -669,10 +669,14 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                     if (exhausted) break;
                     int cand = -1;
                     while (my_bucket < kBuckets) {
-                        int idx = 0;
-                        if (w.gl == 0) idx = atomicAdd(&cq.bucket_pop[my_bucket], 1);
+                        // look before popping: an atomic on a class that is empty or drained is one of ~12,000
+                        // (every group comes by) serialised on one address -- 4 ms of a 55 ms launch with 32 empty classes
+                        const int cnt = cq.bucket_count[my_bucket];
+                        int idx = cnt;
+                        if (w.gl == 0 && __hip_atomic_load(&cq.bucket_pop[my_bucket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt)
+                            idx = atomicAdd(&cq.bucket_pop[my_bucket], 1);
                         idx = __shfl(idx, 0, LANES);
-                        if (idx < cq.bucket_count[my_bucket]) {
+                        if (idx < cnt) {
                             cand = cq.live[(size_t)my_bucket * cq.live_stride + idx];
                             break;
                         }

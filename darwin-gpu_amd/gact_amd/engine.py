@@ -141,6 +141,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    global LIB_PATH
+    LIB_PATH = os.environ.get("GACT_HIP_LIB_PATH", LIB_PATH)        # A/B measurements of two builds in one GPU call
     if not os.path.exists(LIB_PATH):
         raise GactHipError("%s is missing: run __graft_entry__.build() (hipcc) first; "
                            "this engine has no CPU fallback" % LIB_PATH)

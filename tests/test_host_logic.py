@@ -41,7 +41,7 @@ def test_length_classes_and_kernel_predicates(tmp_path):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(ROOT, "darwin-gpu_amd", "csrc"), "-o", exe, str(tmp_path / "t.hip")])
     out = subprocess.check_output([exe], text=True).split("\n")
-    assert out[0] == "classes 1 0 15 16 31"         # monotone, one tile wide up to 15, everything long in the last one
+    assert out[0] == "classes 1 0 15 16 63"         # monotone, one tile wide up to 15, everything very long in the last one
     assert out[1] == "default 1 1 1"
     assert out[2] == "large 0"
     assert out[3] == "mid 1 0 0"                    # packed main kernel yes; int32 seed kernel, explicit pointer comparisons

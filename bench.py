@@ -40,29 +40,47 @@ def host_cores():
     return n
 
 
-def pmc_traffic(workload_name, candidates, kernel, cells):
-    """(bytes per launch, where from) of the dominant kernel from the newest committed PMC summary that was taken
-    on the same workload, candidate source, kernel and cell count; (None, None) otherwise.  WRITE_SIZE / FETCH_SIZE
-    are KiB; FETCH_SIZE is taken as reported (MI355X_MICROARCH.md: exact x2 for wide streaming reads, uncalibrated
-    for this kernel's 16-byte sc1 loads, so the read share is 1-2x the figure)."""
+def pmc_lookup(workload_name, candidates, kernel, cells):
+    """Counters of the dominant kernel from the newest committed PMC summary (profiles/r*/pmc_*.json, written by
+    tools/pmc_summary.py from scripts/gpu_pmc.sh: separate rocprofv3 --pmc passes of this same command) that was
+    taken on the same workload, candidate source, kernel and cell count; None otherwise.  HBM bytes cannot be
+    counted from inside this process, and neither can executed instructions."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    if workload_name != "ecoli10x" or candidates != "dsoft":
-        return None, None
-    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_round_end_ecoli10x.json")), reverse=True):
+    if candidates != "dsoft":
+        return None
+    paths = sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_*%s*.json" % workload_name)),
+                   key=lambda q: (os.path.basename(os.path.dirname(q)), os.path.getmtime(q)), reverse=True)
+    for path in paths:
         try:
             d = json.load(open(path))
-            wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if k.startswith("extend") and "WRITE_SIZE" in v)
-            rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if k.startswith("extend") and "FETCH_SIZE" in v)
-            b = d["write"]["_bench"]
+            b = d["sq"]["_bench"]
             if b["kernel"] != kernel or b["kernel_cells"] != cells:
                 continue
-            return int((wr + rd) * 1024), os.path.relpath(path, here) + \
-                " (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE, separate passes of this command; %.1f GB written + " \
-                "%.1f GB read as reported)" % (wr * 1024 / 1e9, rd * 1024 / 1e9)
+            sq = next(v for k, v in d["sq"].items() if k.startswith("extend"))
+            wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if k.startswith("extend") and "WRITE_SIZE" in v)
+            rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if k.startswith("extend") and "FETCH_SIZE" in v)
+            return {"source": os.path.relpath(path, here), "insts_valu": sq["SQ_INSTS_VALU"],
+                    "gui_active": sq["GRBM_GUI_ACTIVE"], "write_kib": wr, "fetch_kib": rd,
+                    "profiled_kernel_ms": b["kernel_ms"]}
         except (OSError, KeyError, StopIteration, ValueError):
             continue
-    return None, None
+    return None
+
+
+# Algorithmic work of the main launch, per DP cell, in lane-op slots (DESIGN.md 3.6).  One slot = one lane of one
+# wave64 VALU instruction; the kernels work on int16 pairs, two cells per slot.  Per cell PAIR the recurrence of
+# align.cpp:134-160 needs, in the cheapest formulation known for the scoring in use,
+#   affine gaps (any scoring):          11 ops for the scores, 11 more where traceback pointers are made
+#   linear gaps (open == extend == mismatch, the reference's params.cfg): 8 and 7 more (gact_lin.hpp)
+# and pointers are needed only inside the window a non-first tile's traceback can reach: early x early of
+# tile x tile cells (align.cpp:205), 0.39 at the reference's 320 / 120.  Nothing else is counted: no wavefront
+# skew, no loads, no traceback walk, no chain bookkeeping -- those are what `frac` is there to expose.
+def floor_slots_per_cell(linear, tile, early):
+    score, pointer = (8, 7) if linear else (11, 11)
+    window = (min(early, tile) / tile) ** 2
+    return (score + pointer * window) / 2.0, {"score_ops_per_cell_pair": score, "pointer_ops_per_cell_pair": pointer,
+                                              "pointer_window_fraction": round(window, 4)}
 
 
 def main():
@@ -205,26 +223,46 @@ def main():
                            "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
                            "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutTagged>"}[main_kernel]
         measured_rate = eng.measure_valu_rate()
-        peak_tops = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
-        # HBM bytes of the main launch cannot be counted from inside this process: they come from the separate
-        # rocprofv3 --pmc passes of this same command (scripts/gpu_pmc.sh), committed under profiles/; only used
-        # when they were taken on this workload and this kernel
-        traffic, traffic_source = pmc_traffic(args.workload, args.candidates, main_kernel, main_cells)
+        # issue peak: one wave64 VALU instruction per SIMD per 4 cycles = 64 lane-op slots per CU per clock
+        # (profiles/r02/issue_rate_probe.json: every instruction of the kernels, 4 or more resident waves)
+        peak_slots = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
+        linear = bool(kernel_ms[-1].get("linear_gap"))
+        floor, model = floor_slots_per_cell(linear, 320, 200)
+        achieved = floor * main_cells / (k_ms * 1e-3) / 1e12
+        pmc = pmc_lookup(args.workload, args.candidates, main_kernel, main_cells)
+        executed = traffic = traffic_source = None
+        if pmc:
+            slots = pmc["insts_valu"] * 64.0 / main_cells
+            # GRBM_GUI_ACTIVE counts over the 8 XCDs; 1024 SIMDs, 4 cycles per issue
+            util = pmc["insts_valu"] * 4.0 / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0)
+            executed = {"slots_per_cell": round(slots, 3), "valu_issue_utilisation": round(util, 4),
+                        "floor_over_executed": round(floor / slots, 4), "profiled_kernel_ms": pmc["profiled_kernel_ms"],
+                        "source": pmc["source"] + " (SQ_INSTS_VALU, GRBM_GUI_ACTIVE of this kernel on this workload; "
+                                  "utilisation = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))"}
+            traffic = int((pmc["write_kib"] + pmc["fetch_kib"]) * 1024)
+            traffic_source = pmc["source"] + " (WRITE_SIZE / FETCH_SIZE in separate passes; %.1f GB written + %.1f GB " \
+                "read as reported)" % (pmc["write_kib"] * 1024 / 1e9, pmc["fetch_kib"] * 1024 / 1e9)
         roofline = {
-            # integer-VALU roofline: algorithmic work = 24 int32 ops per DP cell
-            # against the int32 issue rate.  The main kernel runs its score recurrence as packed int16
-            # (two cells per lane-op), so it can exceed 1.0 on this scale; frac_packed16 prices the same
-            # work against the packed issue rate (2 x).
-            "bound": "valu", "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 3),
-            "unit": "TOP/s (int32-equivalent lane-ops, 24 per DP cell)", "frac": round(achieved_tops / peak_tops, 4),
-            "frac_packed16": round(achieved_tops / (2 * peak_tops), 4),
+            # integer-VALU roofline.  achieved = algorithmic lane-op slots (model below) x cells of
+            # the main launch / its HIP-event time; peak = the SIMDs' issue rate; frac <= 1 by construction:
+            # frac = (floor / executed slots per cell) x VALU issue utilisation.
+            "bound": "valu", "achieved": round(achieved, 3), "peak": round(peak_slots, 3),
+            "unit": "T lane-op slots/s (one lane of one wave64 VALU instruction; int16 pairs: two DP cells per slot)",
+            "frac": round(achieved / peak_slots, 4),
+            "model": dict(model, slots_per_cell=round(floor, 3), scoring="linear gaps" if linear else "affine gaps"),
+            "executed": executed,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": main_kernel,
             "kernel_ms": round(float(k_ms), 3),
             "kernel_cells": main_cells, "seed_kernel": {"packed16": "seed_p16_kernel<20>", "int32": "extend_kernel<20>"}[kernel_ms[-1]["seed_layout"]],
             "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
             "measured_valu_peak_tops": round(measured_rate / 1e12, 3),
-            "peak_gcups": round(peak_tops * 1e3 / OPS_PER_CELL, 1),
+            # SURVEY.md 8d's first-order figure, kept for continuity: 24 int32 ops per cell against the int32 issue
+            # rate.  It exceeds 1 because the kernel does not execute that work (two cells per lane-op, pointers only
+            # inside the window, arg-max only in first tiles): not a roofline fraction.
+            "survey_24op_int32": {"achieved_tops": round(OPS_PER_CELL * main_cells / (k_ms * 1e-3) / 1e12, 3),
+                                  "ratio_to_int32_issue_peak": round(OPS_PER_CELL * main_cells / (k_ms * 1e-3) / 1e12 / peak_slots, 4),
+                                  "peak_gcups_at_24_ops": round(peak_slots * 1e3 / OPS_PER_CELL, 1)},
             "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
             "waves_per_cu": info["waves_per_cu"],
         }

@@ -21,16 +21,39 @@
 //    carries the score of the cell it stands on (walk_chain, FMT 3).  It needs H of the start cell (R, Q): every
 //    tile of a wave is delayed so that its last row falls on the wave's last step, and the value is simply what
 //    the lane of column Q holds when the loop ends.
+// 3. Instruction classes.  tools/issue_probe.hip (profiles/r02/issue_rate_probe.json): with three waves on a SIMD
+//    v_add_u32 / v_sub_u32 / v_and_b32 / v_or_b32 / v_xor_b32 / v_bitop3_b32 on VGPR operands issue every 1.9
+//    cycles, v_pk_*, v_max_*, v_perm_b32, v_and_or_b32, v_mad_*, DPP moves and anything with an SGPR operand every
+//    3.2-3.4.  So the frame is shifted up (kLinBase) until every value is a positive int16: the packed additions
+//    then cannot carry or borrow across the half-words and run as plain 32-bit v_add_u32 / v_sub_u32, -INF becomes 0,
+//    the re-taggings are written so that the compiler takes v_bitop3_b32, and the constants sit in VGPRs.
 #pragma once
 
 #include "gact_p16s.hpp"
 
 namespace gact {
 
+// zero level of lane 0 before step 1: above 31 lanes' worth of drift plus one gap, so nothing ever goes below |g|
+__host__ __device__ constexpr int lin_base(int g) { return 40 * (-g) + 8; }
+// a wave-uniform constant the compiler must keep in a VGPR (an SGPR operand would put the instruction in the slow class)
+// (a & ~b) | c on the fast logic path (the compiler folds the pattern into v_and_or_b32, which is not)
+__device__ __forceinline__ uint32_t andn_or(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xdc" : "=v"(r) : "v"(a), "v"(c), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t vconst(uint32_t s)
+{
+    uint32_t r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s));
+    return r;
+}
+
 // every score, times four, plus the drift of up to kMaxSteps + lanes + lag rows must fit int16
 __host__ inline bool p16_lin_ok(int tile, int match, int mismatch, int open, int ext)
 {
-    const long long steps = (long long)tile + 4 * kGroup + 64;
+    const long long steps = (long long)tile + 4 * kGroup + 64 + 48;        // drift of the longest pass + lin_base
     return open == ext && mismatch == ext && ext <= 0 && match >= 0 &&
            p16_tagged_ok(tile, match, mismatch, open, ext) &&
            4 * ((long long)match * (tile + 2) + (long long)(-ext) * steps) + 3 <= 30000 && match - ext <= 63;
@@ -57,20 +80,23 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     constexpr int QD = (C2 + 3) / 4;
     constexpr int LAG = kGroup;
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
+    const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), t1v = vconst(kc.tag1),
+                   t2v = vconst(kc.tag2);
+    constexpr uint32_t kLow = 0;                        // stands for -INF: below every value of the shifted frame
     // zero level of the row a lane did "before step 1": region 1 is at row t - gl, region 2 at row t - gl - LAG
-    uint32_t Z1 = pk2(gl * g), Z2 = pk2((gl + LAG) * g);
+    uint32_t Z1 = pk2(lin_base(g) + gl * g), Z2 = pk2(lin_base(g) + (gl + LAG) * g);
     uint32_t G[CT], Mp[CT], I[CT];          // H, M of the previous row; I of the previous row (all drifted)
     uint32_t accO[QD * 4], accF[QD * 4];
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-        G[c] = c < C1 ? Z1 : Z2; Mp[c] = G[c]; I[c] = kc.ninf;
+        G[c] = c < C1 ? Z1 : Z2; Mp[c] = G[c]; I[c] = kLow;
     }
 #pragma unroll
     for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
-    uint32_t M1 = Z1, D1 = kc.ninf, H1 = Z1;            // last slot of each region as the neighbour lane will see it
-    uint32_t M2 = Z2, D2 = kc.ninf, H2 = Z2;
+    uint32_t M1 = Z1, D1 = kLow, H1 = Z1;               // last slot of each region as the neighbour lane will see it
+    uint32_t M2 = Z2, D2 = kLow, H2 = Z2;
     uint32_t Hdiag1 = Z1, Hdiag2 = Z2;
-    uint32_t Dl1 = kc.ninf;                             // lane 0 keeps the j = 0 border: D = -INF
+    uint32_t Dl1 = kLow;                                // lane 0 keeps the j = 0 border: D = -INF
 
     auto lut = [&](uint32_t amount) { return kc.dsub >> (amount & 31u); };
     auto lut4 = [&](uint32_t amount) { return kc.dsub4 >> (amount & 31u); };
@@ -83,13 +109,13 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     // region 1, both phases: plain drifted scores
     // (Mp[c] turns from the previous row's M into this row's M in place: no register is copied)
     auto r1_first = [&](uint32_t &Hd, int c) {
-        const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(rb1b, rb1, qb[c]));     // align.cpp:134-144
+        const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb1b, rb1, qb[c]);            // align.cpp:134-144 (no carry)
         Hd = G[c];
         I[c] = pk_max(Mp[c], I[c]);                                                  // :149-154
         Mp[c] = pk_max(Mx, Z1);                                                      // :145-147
     };
     auto r1_second = [&](uint32_t &Ml, uint32_t &Dl, int c) {
-        const uint32_t D = pk_add_s(pk_max(Ml, Dl), kc.ext);                         // :151-156
+        const uint32_t D = pk_max(Ml, Dl) - gv;                                      // :151-156 (no borrow)
         G[c] = pk_max(pk_max(Mp[c], I[c]), D);                                       // :158-160
         Ml = Mp[c];
         Dl = D;
@@ -97,7 +123,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
 
     auto step = [&](const int t) {
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
-        Z1 = pk_add_s(Z1, kc.next); Z2 = pk_add_s(Z2, kc.next);
+        Z1 += gv; Z2 += gv;
         // lane 0 of region 1 sits on the j = 0 border: M = H = 0 (the zero level), D = -INF
         const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)M1, (int)Z1);
         Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
@@ -112,7 +138,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         for (int c = 0; c < CT; c++) {
             if (c < C1) { r1_first(Hd, c); continue; }
             if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(rb2b, rb2, qb[c]));
+            const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb2b, rb2, qb[c]);
             Hd = G[c];
             I[c] = pk_max(Mp[c], I[c]);
             Mp[c] = pk_max(Mx, Z2);
@@ -132,10 +158,9 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
 
     // ---- pointer phase: region 2 on tagged scores.  Registers: G = 4H+3, Mp = 4M+3, I = 4I+2 (all drifted).
     uint32_t Z24 = 0;
-    const uint32_t vmask = kc.nmask;
     auto step_tagged = [&](const int t) {
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
-        Z1 = pk_add_s(Z1, kc.next); Z24 = pk_add_s(Z24, kc.next4);
+        Z1 += gv; Z24 += g4v;
         const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)M1, (int)Z1);
         Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
@@ -149,7 +174,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         for (int c = 0; c < CT; c++) {
             if (c < C1) { r1_first(Hd, c); continue; }
             if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(rb2b, rb2, qb[c]));     // 4(H[i-1][j-1] + sub) + 3
+            const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb2b, rb2, qb[c]);            // 4(H[i-1][j-1] + sub) + 3
             Hd = G[c];
             I[c] = pk_max(Mp[c], I[c]);                      // low bits 3: ins_open >= ins_extend (:170), 2: not
             Mp[c] = pk_max(Mx, Z24);                                                     // 4M + 3, M >= 0
@@ -163,12 +188,12 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
             }
             if (c < C1) { r1_second(Ml, Dl, c); continue; }
             const uint32_t Dp = pk_max(Ml, Dl);              // low bits 3: del_open >= del_extend (:171), 1: not
-            const uint32_t Dt = and_or(pk_add_s(Dp, kc.ext4), vmask, kc.tag1);
-            const uint32_t It = and_or(I[c], vmask, kc.tag2);
+            const uint32_t Dt = andn_or(Dp - g4v, c3v, t1v);
+            const uint32_t It = andn_or(I[c], c3v, t2v);
             const uint32_t Hp = pk_max(pk_max(Mp[c], It), Dt);                           // :158-168
-            accF[c - C1] = pk_shl_add4(accF[c - C1], (I[c] ^ Dp) & kc.c3);
-            accO[c - C1] = pk_shl_add4(accO[c - C1], Hp & kc.c3);
-            G[c] = Hp | kc.c3;
+            accF[c - C1] = pk_shl_add4(accF[c - C1], (I[c] ^ Dp) & c3v);
+            accO[c - C1] = pk_shl_add4(accO[c - C1], Hp & c3v);
+            G[c] = Hp | c3v;
             I[c] = It;
             Ml = Mp[c];
             Dl = Dt;
@@ -181,10 +206,10 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         for (int c = C1; c < CT; c++) {
             G[c] = pk_mad4(G[c], kc.c3);
             Mp[c] = pk_mad4(Mp[c], kc.c3);
-            I[c] = pk_mad4(pk_max_s(I[c], kc.floor4), kc.tag2);
+            I[c] = pk_mad4(I[c], kc.tag2);
         }
         M2 = pk_mad4(M2, kc.c3);
-        D2 = pk_mad4(pk_max_s(D2, kc.floor4), kc.tag1);
+        D2 = pk_mad4(D2, kc.tag1);
         H2 = pk_mad4(H2, kc.c3);
         Hdiag2 = pk_mad4(Hdiag2, kc.c3);
         Z24 = pk_mad4(Z2, kc.c3);
@@ -251,14 +276,17 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     constexpr int QD = (C + 3) / 4;
     static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
-    uint32_t Z = pk2(gl * g);                    // zero level of the row this lane did "before step 1"
+    const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), t1v = vconst(kc.tag1),
+                   t2v = vconst(kc.tag2);
+    constexpr uint32_t kLow = 0;                 // stands for -INF (see dp_pass_lin_split)
+    uint32_t Z = pk2(lin_base(g) + gl * g);      // zero level of the row this lane did "before step 1"
     uint32_t G[C], Mp[C], I[C];
     uint32_t accO[QD * 4], accF[QD * 4];
 #pragma unroll
-    for (int c = 0; c < C; c++) { G[c] = Z; Mp[c] = Z; I[c] = kc.ninf; }
+    for (int c = 0; c < C; c++) { G[c] = Z; Mp[c] = Z; I[c] = kLow; }
 #pragma unroll
     for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
-    uint32_t M_last = Z, D_last = kc.ninf, G_last = Z, Hdiag = Z, Dl0 = kc.ninf;
+    uint32_t M_last = Z, D_last = kLow, G_last = Z, Hdiag = Z, Dl0 = kLow;
 
     // arg-max state (see dp_pass_p16)
     uint32_t bk[AMAX ? C : 1];
@@ -285,7 +313,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 
     auto step = [&](const int t) {
         const uint32_t w_next = ref16[t + 1];
-        Z = pk_add_s(Z, kc.next);
+        Z += gv;
         const uint32_t Ml0 = shr1(M_last, Z);
         Dl0 = shr1(D_last, Dl0);
         const uint32_t Hl = shr1(G_last, Z);
@@ -293,7 +321,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         Hdiag = Hl;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(lutB, lutA, qb[c]));
+            const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
             Hd = G[c];
             I[c] = pk_max(Mp[c], I[c]);
             Mp[c] = pk_max(Mx, Z);
@@ -301,7 +329,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         uint32_t Ml = Ml0, Dl = Dl0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t D = pk_add_s(pk_max(Ml, Dl), kc.ext);
+            const uint32_t D = pk_max(Ml, Dl) - gv;
             G[c] = pk_max(pk_max(Mp[c], I[c]), D);
             Ml = Mp[c];
             Dl = D;
@@ -311,13 +339,12 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     };
 
     uint32_t Z4 = 0, Z8 = 0;
-    const uint32_t vmask = kc.nmask;
     auto step_tagged = [&](const int t) {
         const uint32_t w_next = ref16[t + 1];
-        Z4 = pk_add_s(Z4, kc.next4);
+        Z4 += g4v;
         uint32_t key_c = 0;
         if (AMAX) {
-            Z8 = pk_add_s(pk_add_s(Z8, kc.next4), kc.next4);
+            Z8 += g4v + g4v;
             const uint32_t sidx = (uint32_t)(t - tB) & 7u, row0 = (uint32_t)(t - t_first);
             const uint32_t ka = row0 < (uint32_t)rows[0] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
             const uint32_t kb = row0 < (uint32_t)rows[1] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
@@ -330,7 +357,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         Hdiag = Hl;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t Mx = pk_add(Hd, __builtin_amdgcn_perm(lutB, lutA, qb[c]));
+            const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
             Hd = G[c];
             I[c] = pk_max(Mp[c], I[c]);
             Mp[c] = pk_max(Mx, Z4);
@@ -339,12 +366,12 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const uint32_t Dp = pk_max(Ml, Dl);
-            const uint32_t Dt = and_or(pk_add_s(Dp, kc.ext4), vmask, kc.tag1);
-            const uint32_t It = and_or(I[c], vmask, kc.tag2);
+            const uint32_t Dt = andn_or(Dp - g4v, c3v, t1v);
+            const uint32_t It = andn_or(I[c], c3v, t2v);
             const uint32_t Hp = pk_max(pk_max(Mp[c], It), Dt);
-            accF[c] = pk_shl_add4(accF[c], (I[c] ^ Dp) & kc.c3);
-            accO[c] = pk_shl_add4(accO[c], Hp & kc.c3);
-            G[c] = Hp | kc.c3;
+            accF[c] = pk_shl_add4(accF[c], (I[c] ^ Dp) & c3v);
+            accO[c] = pk_shl_add4(accO[c], Hp & c3v);
+            G[c] = Hp | c3v;
             if (AMAX) bk[c] = pk_max(bk[c], pk_mad_vvv(G[c], kc.tag2, key_c));      // 2 G'' + (step & 7) - 2 Z''
             I[c] = It;
             Ml = Mp[c];
@@ -358,11 +385,11 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         for (int c = 0; c < C; c++) {
             G[c] = pk_mad4(G[c], kc.c3);
             Mp[c] = pk_mad4(Mp[c], kc.c3);
-            I[c] = pk_mad4(pk_max_s(I[c], kc.floor4), kc.tag2);
+            I[c] = pk_mad4(I[c], kc.tag2);
         }
         M_last = pk_mad4(M_last, kc.c3);
-        D_last = pk_mad4(pk_max_s(D_last, kc.floor4), kc.tag1);
-        Dl0 = pk_mad4(pk_max_s(Dl0, kc.floor4), kc.tag1);
+        D_last = pk_mad4(D_last, kc.tag1);
+        Dl0 = pk_mad4(Dl0, kc.tag1);
         G_last = pk_mad4(G_last, kc.c3);
         Hdiag = pk_mad4(Hdiag, kc.c3);
         Z4 = pk_mad4(Z, kc.c3);

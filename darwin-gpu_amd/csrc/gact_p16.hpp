@@ -569,6 +569,128 @@ __device__ __forceinline__ void load_pair(const SeqSetDev &rs, const SeqSetDev &
 }
 
 // ---------------------------------------------------------------------------
+// The same for 2-bit sets, without the per-base loads: a tile's ref and query slices are at most 21 packed words
+// each, so the group's lanes copy those words into an LDS staging area (one or two coalesced loads per lane and
+// slice, all in flight at once) and every lane then cuts its bases out of LDS.  load_pair / load_pair_split issue
+// one global load per base -- 160 per lane -- into register arrays that do not fit next to the DP state of the
+// chain kernels: the compiler spilled them, waiting for every load before storing it to scratch, ~70 serialised
+// memory round trips per pass, a fifth of a wave's time in the main launch.
+// COL(gl, s, Q) = 0-based DP column of slot s (negative: a pad column left of the tile); rows are dealt to the
+// loader's slots as gl * CT + s.
+// Staged slice of a tile: two spare words in front (a run read back to front may begin up to CT - 1 bases before
+// the slice), the slice's own words (it starts anywhere inside its first word), three behind (a 32-base window
+// may reach past its end).
+template <int CT, int LANES> struct StageGeom {
+    static constexpr int kFront = 2;
+    static constexpr int kSeg = kFront + CT * LANES / 16 + 1 + 3;
+    static constexpr int kWords = 4 * kSeg;         // {tile A, tile B} x {ref, query}
+};
+
+// N consecutive DP indices d0 .. d0+N-1 of a slice of `len` bases whose first base sits `bit0` bases into the
+// staged words: their 2-bit codes, cut out of one 64-bit window (three LDS words, two funnel shifts, one
+// v_bfe per code) instead of one LDS read per base.  Read back to front when `reverse` (align.cpp:130-131).
+// Codes of indices outside 0..len-1 are garbage; the caller masks them.
+template <int N, int KFRONT>
+__device__ __forceinline__ void cut_run(const uint32_t *seg_words, int bit0, int len, bool reverse, int d0, uint32_t (&code)[N])
+{
+    static_assert(N <= 32, "one 64-bit window");
+    typedef __attribute__((address_space(3))) const uint32_t LdsWord;
+    LdsWord *st = (LdsWord *)seg_words;
+    // lowest base of the run, in staged coordinates (front padding included)
+    const int lo = imax(16 * KFRONT + bit0 + (reverse ? len - d0 - N : d0), 0);
+    const int wi = lo >> 4;
+    const uint32_t sh = 2u * (uint32_t)(lo & 15);
+    const uint32_t w0 = st[wi], w1 = st[wi + 1], w2 = st[wi + 2];
+    const uint32_t x_lo = __builtin_amdgcn_alignbit(w1, w0, sh), x_hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int p = reverse ? N - 1 - k : k;          // position of index d0 + k inside the window
+        // (a select between two compile-time positions, not a variable shift)
+        const uint32_t fwd = k < 16 ? (x_lo >> (2 * k)) & 3u : (x_hi >> (2 * (k - 16))) & 3u;
+        const int pr = N - 1 - k;
+        const uint32_t rev = pr < 16 ? (x_lo >> (2 * pr)) & 3u : (x_hi >> (2 * (pr - 16))) & 3u;
+        (void)p;
+        code[k] = reverse ? rev : fwd;
+    }
+}
+
+// COL::runs: the lane's slots as runs of consecutive DP columns -- first slot, slot count, and the column of the
+// run's first slot (which may be negative: pad columns left of the tile).
+template <int CT, int LANES, class COL>
+__device__ __forceinline__ void load_pair_packed(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc,
+                                                 const PairTile &pt, int gl, uint8_t *ref8, int ref_bytes, int row0,
+                                                 uint8_t *q8, int q_stride, uint32_t (&qb)[CT], uint32_t *stage, COL)
+{
+    using SG = StageGeom<CT, LANES>;
+    constexpr int kStageSeg = SG::kSeg;
+    GACT_STAMP(l_a);
+    uint32_t *ref32 = reinterpret_cast<uint32_t *>(ref8);
+    for (int k = gl; k < ref_bytes / 4; k += LANES) ref32[k] = kLutPadRow * 0x01010101u;
+#pragma unroll
+    for (int seg = 0; seg < 4; seg++) {
+        const int h = seg >> 1;
+        const bool is_q = seg & 1;
+        const uint32_t *words = is_q ? (pt.comp[h] ? qrc.packed : qfwd.packed) : rs.packed;
+        const int64_t p0 = is_q ? pt.qp0[h] : pt.rp0[h];
+        const int len = imax(is_q ? pt.Q[h] : pt.R[h], 1);
+        const int64_t w0 = p0 >> 4;
+        const int last = (int)(((p0 + len - 1) >> 4) - w0);
+        for (int k = gl; k < kStageSeg - SG::kFront; k += LANES)
+            stage[seg * kStageSeg + SG::kFront + k] = words[w0 + imin(k, last)];
+    }
+    wave_sync();
+    GACT_STAMP(l_b);
+#pragma unroll
+    for (int h = 0; h < kSlots; h++) {
+        const int R = pt.R[h], Q = pt.Q[h];
+        const bool rev = pt.reverse[h];
+        // ---- ref stream: DP rows gl * CT .. + CT - 1 of this tile.  Row R's entry is a pad row: rows past the
+        //      tile write the pad there, so the stores need no predicate
+        uint8_t *rrow = ref8 + (row0 + pt.shift[h]) * 2 + h;
+        uint32_t rc[CT];
+        cut_run<CT, SG::kFront>(stage + (2 * h) * kStageSeg, (int)(pt.rp0[h] & 15), R, rev, gl * CT, rc);
+#pragma unroll
+        for (int s = 0; s < CT; s++) {
+            const int d = gl * CT + s;
+            rrow[imin(d, R) * 2] = (uint8_t)(d < R ? 24u - rc[s] * 8u : kLutPadRow);
+        }
+        // ---- query: the walker's byte per column, and the slot's v_perm selector
+        const uint32_t *qseg = stage + (2 * h + 1) * kStageSeg;
+        const int qbit0 = (int)(pt.qp0[h] & 15);
+        auto run = [&](auto first_tag, auto n_tag) {
+            constexpr int S0 = decltype(first_tag)::value, N = decltype(n_tag)::value;
+            const int c0 = COL::column(gl, S0, Q);
+            uint32_t qc[N];
+            cut_run<N, SG::kFront>(qseg, qbit0, Q, rev, c0, qc);
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const int dq = c0 + k;
+                const bool real = (unsigned)dq < (unsigned)Q;
+                if (real) q8[h * q_stride + dq] = (uint8_t)(24u - qc[k] * 8u);
+                const uint32_t keep = h ? 0xff00ffffu : 0xffffff00u;
+                const uint32_t mine = (h ? qb[S0 + k] : kPermZero * 0x01010101u);       // tile A initialises the selector
+                qb[S0 + k] = real ? (mine & keep) | ((qc[k] + 4u * h) << (16 * h)) : mine;
+            }
+        };
+        COL::for_each_run(run);
+    }
+#ifdef GACT_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GACT_STAMP(l_c);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_stamps2[4], l_b - l_a); atomicAdd(&g_stamps2[5], l_c - l_b); atomicAdd(&g_stamps2[6], 1ull);
+    }
+#endif
+}
+
+// the uniform layouts: one run of C consecutive columns per lane
+template <int C> struct UniformCols {
+    __device__ static int column(int gl, int slot, int Q) { (void)Q; return gl * C + slot; }
+    template <class F> __device__ static void for_each_run(F &&f)
+    { f(std::integral_constant<int, 0>{}, std::integral_constant<int, C>{}); }
+};
+
+// ---------------------------------------------------------------------------
 // Column layout policy of the packed pass: how a tile's columns map to (lane, slot),
 // which pass / loader go with it, and where the walker finds a cell's pointer word.
 template <int C, int LANES = kGroup, bool TAG = false> struct UniformLayout {
@@ -585,8 +707,12 @@ template <int C, int LANES = kGroup, bool TAG = false> struct UniformLayout {
     __device__ static int first_pointer_step(int R, int Q, int early) { return gact::first_pointer_step<C>(R, Q, early, false); }
     template <bool RAW>
     __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr,
-                                const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C])
-    { load_pair<C, RAW, LANES>(rs, qf, qr, pt, gl, ref8, q8, qb); }
+                                const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C], uint32_t *stage)
+    {
+        if (RAW) load_pair<C, RAW, LANES>(rs, qf, qr, pt, gl, ref8, q8, qb);
+        else load_pair_packed<C, LANES>(rs, qf, qr, pt, gl, ref8, G::kRefBytes, kRow0, q8, G::kTileMax, qb, stage,
+                                        UniformCols<C>{});
+    }
     template <bool RAW>
     __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C], int T_end,
                                     int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &)
@@ -619,6 +745,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
     __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
+    __shared__ uint32_t stage_lds[kGroupsPerBlock][StageGeom<L::kSlotsPerLane, LANES>::kWords];
 
     WaveCtx w;
     {
@@ -719,7 +846,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
 
         GACT_STAMP(t_b);
         uint32_t qb[L::kSlotsPerLane];
-        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb);
+        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb, stage_lds[group_in_block]);
         wave_sync();
         GACT_STAMP(t_c);
 
@@ -830,6 +957,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
     __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
+    __shared__ uint32_t stage_lds[kGroupsPerBlock][StageGeom<C, kGroup>::kWords];
 
     const WaveCtx w = wave_ctx();
     const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
@@ -884,7 +1012,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
         const int T_end = wave_max4(imax(L::last_step(pt.R[0], pt.Q[0]), L::last_step(pt.R[1], pt.Q[1])));
 
         uint32_t qb[C];
-        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb);
+        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb, stage_lds[group_in_block]);
         wave_sync();
 
         P16Best pb;

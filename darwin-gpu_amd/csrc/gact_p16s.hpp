@@ -360,8 +360,25 @@ template <int C1, int C2, bool TAG = false> struct SplitLayout {
     __device__ static int first_pointer_step(int R, int Q, int early) { return split_first_pointer_step<C2>(R, Q, early); }
     template <bool RAW>
     __device__ static void load(const SeqSetDev &rs, const SeqSetDev &qf, const SeqSetDev &qr,
-                                const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C1 + C2])
-    { load_pair_split<C1, C2, RAW>(rs, qf, qr, pt, gl, ref8, q8, qb); }
+                                const PairTile &pt, int gl, uint8_t *ref8, uint8_t *q8, uint32_t (&qb)[C1 + C2], uint32_t *stage)
+    {
+        if (RAW) load_pair_split<C1, C2, RAW>(rs, qf, qr, pt, gl, ref8, q8, qb);
+        else load_pair_packed<C1 + C2, kGroup>(rs, qf, qr, pt, gl, ref8, G::kRefBytes, G::kRow0, q8, G::kTileMax, qb, stage,
+                                               Cols{});
+    }
+    // a lane's slots are two runs of consecutive columns: C1 of region 1, C2 of region 2 (right-aligned tile)
+    struct Cols {
+        __device__ static int column(int gl, int slot, int Q)
+        {
+            const int p = (slot < C1) ? gl * C1 + slot + 1 : G::W1 + gl * C2 + (slot - C1) + 1;     // padded column
+            return p - (G::kTileMax - Q) - 1;
+        }
+        template <class F> __device__ static void for_each_run(F &&f)
+        {
+            f(std::integral_constant<int, 0>{}, std::integral_constant<int, C1>{});
+            f(std::integral_constant<int, C1>{}, std::integral_constant<int, C2>{});
+        }
+    };
     template <bool RAW>
     __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
                                     int T_end, int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &)

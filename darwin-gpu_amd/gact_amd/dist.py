@@ -84,7 +84,7 @@ class DeviceRecords:
     copy: the CUDA array interface, which torch.as_tensor honours on ROCm as well."""
 
     def __init__(self, ptr, n, itemsize):
-        self.__cuda_array_interface__ = {"shape": (int(n), int(itemsize)), "typestr": "|u1", "data": (int(ptr), True),
+        self.__cuda_array_interface__ = {"shape": (int(n), int(itemsize)), "typestr": "|u1", "data": (int(ptr), False),
                                          "version": 2, "strides": None}
 
 

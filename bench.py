@@ -20,12 +20,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "darwin-gpu_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
-OPS_PER_CELL = 24            # 11 score + 10 pointer + 3 arg-max int32 ops
-# int32 VALU issues 64 lanes per CU per clock on gfx950 (4 SIMDs x 16 lanes: a wave64
-# v_add_u32 / v_max_i32 takes 4 cycles; measured by gact_hip_measure_valu_rate).
-# The 157.3 TFLOP/s fp32 figure of MI355X_MICROARCH.md is 2 flop x 128 lanes and does not
-# apply to integer add/max/compare.
-NOMINAL_LANES_PER_CU_CLK = 64
+OPS_PER_CELL = 24            # 11 score + 10 pointer + 3 arg-max int32 ops (kept as a secondary figure)
+# VALU issue peak of gfx950: four SIMD-32 per CU, a wave64 instruction every 2 cycles = 128 lane-op slots per CU per
+# clock (MI355X_MICROARCH.md; the 157.3 TFLOP/s fp32 vector figure is 2 flop x this).  tools/issue_probe.hip
+# (profiles/r02/issue_rate_probe.json) measures what a SIMD really issues: v_add_u32 / v_and_b32 / v_bitop3_b32 /
+# v_fma_f32 reach 1.5 cycles with eight resident waves, the packed-int16, max, perm and DPP instructions this
+# kernel is mostly made of 2.5-2.8 cycles (3.2-3.4 with the three waves its register budget allows).  Round 1
+# priced against 4 cycles per instruction (64 lanes per CU per clock); that was the rate of ITS probe's dependent
+# pairs on few waves, not the machine's.
+NOMINAL_LANES_PER_CU_CLK = 128
+ISSUE_CYCLES = 2
 
 
 def host_cores():
@@ -223,8 +227,7 @@ def main():
                            "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
                            "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutTagged>"}[main_kernel]
         measured_rate = eng.measure_valu_rate()
-        # issue peak: one wave64 VALU instruction per SIMD per 4 cycles = 64 lane-op slots per CU per clock
-        # (profiles/r02/issue_rate_probe.json: every instruction of the kernels, 4 or more resident waves)
+        # issue peak: one wave64 VALU instruction per SIMD per 2 cycles = 128 lane-op slots per CU per clock
         peak_slots = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
         linear = bool(kernel_ms[-1].get("linear_gap"))
         floor, model = floor_slots_per_cell(linear, 320, 200)
@@ -233,12 +236,12 @@ def main():
         executed = traffic = traffic_source = None
         if pmc:
             slots = pmc["insts_valu"] * 64.0 / main_cells
-            # GRBM_GUI_ACTIVE counts over the 8 XCDs; 1024 SIMDs, 4 cycles per issue
-            util = pmc["insts_valu"] * 4.0 / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0)
+            # GRBM_GUI_ACTIVE counts over the 8 XCDs; 1024 SIMDs, 2 cycles per issue at the peak
+            util = pmc["insts_valu"] * float(ISSUE_CYCLES) / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0)
             executed = {"slots_per_cell": round(slots, 3), "valu_issue_utilisation": round(util, 4),
                         "floor_over_executed": round(floor / slots, 4), "profiled_kernel_ms": pmc["profiled_kernel_ms"],
                         "source": pmc["source"] + " (SQ_INSTS_VALU, GRBM_GUI_ACTIVE of this kernel on this workload; "
-                                  "utilisation = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))"}
+                                  "utilisation = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))"}
             traffic = int((pmc["write_kib"] + pmc["fetch_kib"]) * 1024)
             traffic_source = pmc["source"] + " (WRITE_SIZE / FETCH_SIZE in separate passes; %.1f GB written + %.1f GB " \
                 "read as reported)" % (pmc["write_kib"] * 1024 / 1e9, pmc["fetch_kib"] * 1024 / 1e9)
@@ -256,12 +259,12 @@ def main():
             "kernel_ms": round(float(k_ms), 3),
             "kernel_cells": main_cells, "seed_kernel": {"packed16": "seed_p16_kernel<20>", "int32": "extend_kernel<20>"}[kernel_ms[-1]["seed_layout"]],
             "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
-            "measured_valu_peak_tops": round(measured_rate / 1e12, 3),
-            # SURVEY.md 8d's first-order figure, kept for continuity: 24 int32 ops per cell against the int32 issue
-            # rate.  It exceeds 1 because the kernel does not execute that work (two cells per lane-op, pointers only
-            # inside the window, arg-max only in first tiles): not a roofline fraction.
+            "measured_packed16_issue_tops": round(measured_rate / 1e12, 3),
+            # SURVEY.md 8d's first-order figure, kept for continuity: 24 int32 ops per cell against the issue peak.
+            # The kernel does not execute that work (two cells per lane-op, pointers only inside the window, arg-max
+            # only in first tiles), so this is not a roofline fraction.
             "survey_24op_int32": {"achieved_tops": round(OPS_PER_CELL * main_cells / (k_ms * 1e-3) / 1e12, 3),
-                                  "ratio_to_int32_issue_peak": round(OPS_PER_CELL * main_cells / (k_ms * 1e-3) / 1e12 / peak_slots, 4),
+                                  "ratio_to_issue_peak": round(OPS_PER_CELL * main_cells / (k_ms * 1e-3) / 1e12 / peak_slots, 4),
                                   "peak_gcups_at_24_ops": round(peak_slots * 1e3 / OPS_PER_CELL, 1)},
             "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
             "waves_per_cu": info["waves_per_cu"],

@@ -42,10 +42,7 @@ int gact_hip_dsoft_build(gact_hip_engine *e, const gact_dsoft_params *p, gact_ds
     if (d.ref_len < (uint32_t)(p->seed_size + p->window_size))
         return fail(GACT_HIP_EINVAL, "dsoft_build: reference shorter than one window");
     d.max_occ = (uint32_t)p->seed_occurence_multiple * (1u + (d.ref_len >> (2 * p->seed_size)));   // seed_pos_table.cpp:59
-    if ((int64_t)p->max_candidates < ((int64_t)p->num_seeds + 1) * (int64_t)d.max_occ)
-        return fail(GACT_HIP_EINVAL, "dsoft_build: max_candidates %d could bind (%d seeds x %u occurrences); the device "
-                                     "filter does not reproduce the reference's truncation order, use the host filter",
-                    p->max_candidates, p->num_seeds + 1, d.max_occ);
+    if (p->max_candidates < 1) return fail(GACT_HIP_EINVAL, "dsoft_build: max_candidates must be >= 1");
     d.n_table = 1ull << (2 * p->seed_size);
 
     const uint32_t rlen_2bit = 1 + d.ref_len / 16;                                // :61
@@ -219,6 +216,15 @@ int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int3
         if (attempt > 0 || d.temp.reserve((size_t)used + 1024))
             return fail(GACT_HIP_ENOMEM, "dsoft_query: %llu candidates do not fit the device", used);
     }
+    // seed_pos_table.cpp:141-143: a query strand keeps its first max_candidates threshold crossings, in emission
+    // order.  (What the reference's `break` does beyond that -- hits of the seed it skips, bins it never registers
+    // for clearing and so carries into the NEXT query of the same host thread -- depends on which reads a thread
+    // happens to get and is not reproduced: every query starts from clean bins here.)
+    bool clamped = false;
+    for (int t = 0; t < n_tasks; t++)
+        if (counts[t] > d.p.max_candidates) { counts[t] = d.p.max_candidates; clamped = true; }
+    if (clamped)
+        HIP_TRY(hipMemcpyAsync(d.counts.p, counts.data(), (size_t)n_tasks * sizeof(int32_t), hipMemcpyHostToDevice, sl.stream));
     std::vector<int64_t> base((size_t)n_tasks);
     int64_t run = 0;
     for (int t = 0; t < n_tasks; t++) {

@@ -896,27 +896,29 @@ int gact_hip_measure_valu_rate(gact_hip_engine *e, double *lane_ops_per_s)
     int rc = set_device(e);
     if (rc) return rc;
     Slot &sl = e->slots[0];
-    const int iters = 4096;
-    const int blocks = e->prop.multiProcessorCount * 8;
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
-    float best = 1e30f;
-    for (int rep = 0; rep < 4; rep++) {
-        HIP_TRY(hipEventRecord(a, sl.stream));
+    const int iters = 2048, waves_per_simd = 8;
+    const int blocks = e->prop.multiProcessorCount * waves_per_simd;       // 256 threads = one wave per SIMD of a CU
+    const size_t n_waves = (size_t)blocks * (gact::kBlockThreads / 64);
+    unsigned long long *d_clocks = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_clocks, n_waves * sizeof(unsigned long long)));
+    std::vector<unsigned long long> h(n_waves);
+    double best = 1e300;
+    for (int rep = 0; rep < 3; rep++) {
         hipLaunchKernelGGL(gact::valu_probe_kernel, dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream, iters,
-                           12345 + rep, sl.d_flags);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(b, sl.stream));
-        HIP_TRY(hipEventSynchronize(b));
-        float ms = 0;
-        HIP_TRY(hipEventElapsedTime(&ms, a, b));
-        if (rep > 0 && ms < best) best = ms;
+                           12345 + rep, sl.d_flags, d_clocks);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sl.stream) != hipSuccess ||
+            hipMemcpy(h.data(), d_clocks, n_waves * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) {
+            (void)hipFree(d_clocks);
+            return fail(GACT_HIP_EDEVICE, "valu probe failed");
+        }
+        std::nth_element(h.begin(), h.begin() + h.size() / 2, h.end());
+        if (rep) best = std::min(best, (double)h[h.size() / 2]);
     }
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    const double ops = (double)blocks * gact::kBlockThreads * (double)iters * 16.0 * 2.0;
-    *lane_ops_per_s = ops / (best * 1e-3);
+    (void)hipFree(d_clocks);
+    // median wave: clocks between two of its issues; eight such waves share a SIMD
+    const double wave_interval = best / ((double)iters * 32.0);
+    const double simd_interval = wave_interval / waves_per_simd;
+    *lane_ops_per_s = (double)e->prop.multiProcessorCount * 4.0 * 64.0 * ((double)e->prop.clockRate * 1e3) / simd_interval;
     return 0;
 }
 

@@ -310,25 +310,34 @@ __global__ void revcomp_kernel(const uint8_t *__restrict__ raw, const int64_t *_
 }
 
 // ---------------------------------------------------------------------------
-// Integer-VALU issue-rate probe: 16 independent v_add_u32 / v_max_i32 chains
-// per lane, nothing else.  Gives the measured int32 lane-op/s ceiling the
-// roofline fraction in bench.py is priced against.
-__global__ __launch_bounds__(kBlockThreads) void valu_probe_kernel(int iters, int seed, int *__restrict__ sink)
+// VALU issue-rate probe for the instruction class the packed kernels are made of: 16 independent accumulators,
+// v_pk_max_i16 and v_pk_add_i16 in rotation, nothing else.  gact_hip_measure_valu_rate launches it with eight waves
+// per SIMD: the sustained packed-int16 lane-op rate of this device (tools/issue_probe.hip has the whole table).
+__global__ __launch_bounds__(kBlockThreads) void valu_probe_kernel(int iters, int seed, int *__restrict__ sink,
+                                                                  unsigned long long *__restrict__ wave_clocks)
 {
-    int a[16];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    uint32_t a[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = seed + k + threadIdx.x;
-    const int inc = seed | 1;
+    for (int k = 0; k < 16; k++) a[k] = (uint32_t)(seed + k) + threadIdx.x;
+    uint32_t inc, lim;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(inc) : "s"(seed | 1));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(lim) : "s"(seed));
     for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            asm volatile("v_add_u32 %0, %0, %1\n\tv_max_i32 %0, %0, %2" : "+v"(a[k]) : "v"(inc), "v"(seed));
-        }
+        for (int k = 0; k < 16; k++) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(a[k]) : "v"(inc));
+#pragma unroll
+        for (int k = 0; k < 16; k++) asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[k]) : "v"(lim));
     }
-    int r = 0;
+    asm volatile("s_nop 0" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    uint32_t r = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) r ^= a[k];
-    if (r == 0x7fffffff) sink[0] = r;
+    if (r == 0x7fffffffu) sink[0] = (int)r;
+    // shader clocks this wave took (the launch as a whole also pays for uneven block placement and its own tail)
+    if ((threadIdx.x & 63) == 0) wave_clocks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
 }
 
 }  // namespace gact

@@ -35,7 +35,11 @@ extern "C" {
 #define GACT_HIP_ENOMEM     -3
 #define GACT_HIP_ERANGE     -4   /* descriptor points outside a sequence   */
 
-#define GACT_HIP_MAX_TILE   512  /* largest tile_size the kernels are built for */
+/* Largest tile_size the kernels are built for.  BOUNDARY LIMIT: the reference's CPU AlignWithBT asserts
+ * ref_len, query_len < 2049 (align.h:19, align.cpp:66-67) and its CUDA kernel stops at 324 (cuda_header.h:45);
+ * every caller in the reference passes tile_size = 320 (params.cfg:22).  gact_hip_create refuses larger
+ * values, and the align.h shim refuses tiles beyond it with a message (gact_shim.cpp::AlignWithBT). */
+#define GACT_HIP_MAX_TILE   512
 
 /* traceback states, align.h:23 */
 #define GACT_STATE_Z 0
@@ -220,7 +224,7 @@ typedef struct {
     int32_t threshold;
     int32_t num_seeds;
     int32_t seed_occurence_multiple;
-    int32_t max_candidates;            /* per query strand; must not bind (>= (num_seeds+1) * occurrence cap) */
+    int32_t max_candidates;            /* per query strand: the first max_candidates threshold crossings are kept */
 } gact_dsoft_params;
 
 typedef struct {
@@ -263,8 +267,8 @@ void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);
 /* the slot's hipStream_t as an opaque pointer */
 void *gact_hip_stream(gact_hip_engine *e, int slot);
 
-/* measurement aid: sustained int32 VALU lane-ops/s of this device (add/max
- * chains, no memory), the ceiling roofline fractions are priced against */
+/* measurement aid: sustained lane-ops/s of this device on the packed-int16 instructions the kernels are made of
+ * (independent v_pk_add_i16 / v_pk_max_i16 streams, eight waves per SIMD, no memory) */
 int gact_hip_measure_valu_rate(gact_hip_engine *e, double *lane_ops_per_s);
 
 /* formats the exact bytes of gact.cpp:214-224 */

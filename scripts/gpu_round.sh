@@ -1,9 +1,16 @@
-# one GPU round: tests, bench, rocprofv3 kernel trace of the same bench command
+# one GPU round: the whole -m gpu suite, the default bench, rocprofv3 kernel traces of the three single-GPU
+# workloads (BASELINE configs 2, 3, 5); results under gpurun_out/$TAG (copy what is to be judged into profiles/)
 set -e
-mkdir -p gpurun_out
-timeout -k 10 800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-timeout -k 10 600 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; cat gpurun_out/bench_full.json
+TAG=${TAG:-round}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+timeout -k 10 1100 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > $OUT/pytest.log; cat $OUT/pytest.log
+timeout -k 10 300 python bench.py > $OUT/bench_ecoli10x_n1.json 2> $OUT/bench_ecoli10x.err; cat $OUT/bench_ecoli10x_n1.json
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_r01
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_r01 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.json 2> $GRAFT_REPO_ROOT/gpurun_out/prof_bench.err
-find $GRAFT_REPO_ROOT/gpurun_out/prof_r01 -name "*stats*" | head
+for w in ecoli10x pacbio50mb ont; do
+  rm -rf $OUT/prof_$w
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -- python3 $R/bench.py --workload $w --steps 5 --warmup 2 --cpu-seconds 6 > $OUT/bench_${w}_profiled.json 2> $OUT/prof_$w.err
+  cp $(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$w.csv
+done
+ls $OUT

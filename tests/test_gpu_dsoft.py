@@ -161,6 +161,20 @@ def test_dsoft_device_full_workload_then_gact(oracle):
     eng.close()
 
 
+def test_dsoft_device_max_candidates_truncates_in_emission_order():
+    """seed_pos_table.cpp:141-143: a query strand keeps its first max_candidates threshold crossings"""
+    from gact_amd import synth
+    rs = synth.simulate_reads(60000, coverage=12, seed=123, mean_len=5000, sd_len=1500, min_len=900, max_len=9000)
+    full, _ = device_candidates(rs.reads, seed_size=12)
+    cut, _ = device_candidates(rs.reads, seed_size=12, max_candidates=3)
+    want = []
+    for comp in (0, 1):
+        for q in range(len(rs.reads)):
+            want += [c for c in full if c[1] == q and c[4] == comp][:3]
+    assert cut == want and len(cut) < len(full) and max(sum(1 for c in full if c[1] == q and c[4] == 0)
+                                                         for q in range(len(rs.reads))) > 3
+
+
 def test_dsoft_device_argument_errors():
     from gact_amd import engine
     eng = engine.Engine()
@@ -172,7 +186,7 @@ def test_dsoft_device_argument_errors():
     with pytest.raises(engine.GactHipError):
         eng.dsoft_build(engine.DsoftParams(seed_size=16))
     with pytest.raises(engine.GactHipError):
-        eng.dsoft_build(engine.DsoftParams(max_candidates=100))     # could bind
+        eng.dsoft_build(engine.DsoftParams(max_candidates=0))
     eng.dsoft_build(engine.DsoftParams(seed_size=8))
     with pytest.raises(engine.GactHipError):
         eng.dsoft_query(0, 1)                               # query sets missing

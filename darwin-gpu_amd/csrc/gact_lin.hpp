@@ -1,22 +1,26 @@
 // gact_lin.hpp -- the packed-int16 chain pass for LINEAR gap scoring: gap_open == gap_extend == mismatch =: g
 // (the reference's own params.cfg: +1 / -1 / -1 / -1), 2-bit read sets.  Same cells, same results as
-// dp_pass_p16s / dp_pass_p16 -- fewer instructions per cell: 8 instead of 11 per cell pair for the scores,
-// 16 instead of 22 where pointers are made.
+// dp_pass_p16s / dp_pass_p16 -- fewer instructions per cell: 7 instead of 11 per cell pair for the scores,
+// 14 instead of 22 where pointers are made.
 //
 // 1. Row drift.  Every value of DP row i is kept as X + beta_i with beta_i = -i * g (it grows by |g| per row).
 //    In that frame the recurrence of align.cpp:134-160 loses three additions per cell:
 //      I[i][j] = max(M[i-1][j] + open, I[i-1][j] + ext)   ->  I' = max(M'_up, I'_up)            (open == ext == g)
 //      D[i][j] = max(M[i][j-1] + open, D[i][j-1] + ext)   ->  D' = max(M'_left, D'_left) + g    (same row, same frame)
 //      M[i][j] = max(H[i-1][j-1] + sub, 0)                ->  M' = max(H'_diag + (sub - g), Z)  Z = beta_i: the zero level
+//    and with A := max(M, I), B := max(M, D) -- two of the three maxima H = max(M, I, D) is made of anyway --
+//      I' = A'_up,   D' = B'_left + g,   H' = max(A', D'):
+//    per cell pair perm, add, max (M) | max (A) | sub (D), max (B), max (H) = 7 instructions, and two registers of
+//    state per column slot (H and A of the previous row) instead of three.
 //    sub - g is 0 for a mismatch (mismatch == g) and match - g otherwise: the non-negative byte the look-up word of
 //    dp_pass_p16 already holds, so no bias rides on H any more.  The drift is tied to the step, not to the
 //    tile's row number (rows in front of row 1 are virtual and behave like row 0, gact_device.hpp), so two tiles
 //    with different start delays share it.  -INF never has gap_extend added to it here.
 // 2. Tagged pointers (as dp_pass_p16s, TAG): scores times four, the two low bits say where a value came from.
-//      I'' = max(M''_up tagged 3, I''_up tagged 2)        low bits 3: the insertion was opened here, 2: it goes on
-//      D'' = max(M''_left tagged 3, D''_left tagged 1)    low bits 3: opened, 1: goes on
-//      H'' = max(M'' tagged 3, I'' re-tagged 2, D'' re-tagged 1)   the op in align.h:23 numbering
-//    flags = (I'' ^ D'') & 3 = {bit 0: insertion goes on, bit 1: deletion goes on}.
+//      A'' = max(M'' tagged 3, I'' tagged 2)              next row: low bits 3: the insertion was opened, 2: it goes on
+//      B'' = max(M'' tagged 3, D'' tagged 1)              next column: low bits 3: opened, 1: goes on
+//      H'' = max(A'', D'' tagged 1)                       the op in align.h:23 numbering (M3 I2 D1)
+//    flags = (A''_up ^ (B''_left + 4g)) & 3 = {bit 0: insertion goes on, bit 1: deletion goes on}.
 //    H == 0 shows as op 3 like MATCH (M'' is clamped to the zero level tagged 3): ZERO is left to the walker, which
 //    carries the score of the cell it stands on (walk_chain, FMT 3).  It needs H of the start cell (R, Q): every
 //    tile of a wave is delayed so that its last row falls on the wave's last step, and the value is simply what
@@ -82,21 +86,18 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
     const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), t1v = vconst(kc.tag1),
                    t2v = vconst(kc.tag2);
-    constexpr uint32_t kLow = 0;                        // stands for -INF: below every value of the shifted frame
     // zero level of the row a lane did "before step 1": region 1 is at row t - gl, region 2 at row t - gl - LAG
     uint32_t Z1 = pk2(lin_base(g) + gl * g), Z2 = pk2(lin_base(g) + (gl + LAG) * g);
-    uint32_t G[CT], Mp[CT], I[CT];          // H, M of the previous row; I of the previous row (all drifted)
+    uint32_t G[CT], A[CT];                  // H and max(M, I) of the previous row (drifted)
     uint32_t accO[QD * 4], accF[QD * 4];
 #pragma unroll
-    for (int c = 0; c < CT; c++) {
-        G[c] = c < C1 ? Z1 : Z2; Mp[c] = G[c]; I[c] = kLow;
-    }
+    for (int c = 0; c < CT; c++) { G[c] = c < C1 ? Z1 : Z2; A[c] = G[c]; }       // row 0: M = 0, I = -INF
 #pragma unroll
     for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
-    uint32_t M1 = Z1, D1 = kLow, H1 = Z1;               // last slot of each region as the neighbour lane will see it
-    uint32_t M2 = Z2, D2 = kLow, H2 = Z2;
+    // last slot of each region as the neighbour lane will see it: B = max(M, D) and H.  On the j = 0 border both
+    // are the zero level (M = H = 0, D = -INF)
+    uint32_t B1 = Z1, H1 = Z1, B2 = Z2, H2 = Z2;
     uint32_t Hdiag1 = Z1, Hdiag2 = Z2;
-    uint32_t Dl1 = kLow;                                // lane 0 keeps the j = 0 border: D = -INF
 
     auto lut = [&](uint32_t amount) { return kc.dsub >> (amount & 31u); };
     auto lut4 = [&](uint32_t amount) { return kc.dsub4 >> (amount & 31u); };
@@ -106,110 +107,91 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     }
 
-    // region 1, both phases: plain drifted scores
-    // (Mp[c] turns from the previous row's M into this row's M in place: no register is copied)
-    auto r1_first = [&](uint32_t &Hd, int c) {
-        const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb1b, rb1, qb[c]);            // align.cpp:134-144 (no carry)
+    // a plain slot, both phases of region 1 and the score-only phase of region 2
+    auto first = [&](uint32_t &Hd, uint32_t (&M)[CT], int c, uint32_t la, uint32_t lb, uint32_t Z) {
+        const uint32_t Mx = Hd + __builtin_amdgcn_perm(lb, la, qb[c]);               // align.cpp:134-144 (no carry)
         Hd = G[c];
-        I[c] = pk_max(Mp[c], I[c]);                                                  // :149-154
-        Mp[c] = pk_max(Mx, Z1);                                                      // :145-147
+        M[c] = pk_max(Mx, Z);                                                        // :145-147
     };
-    auto r1_second = [&](uint32_t &Ml, uint32_t &Dl, int c) {
-        const uint32_t D = pk_max(Ml, Dl) - gv;                                      // :151-156 (no borrow)
-        G[c] = pk_max(pk_max(Mp[c], I[c]), D);                                       // :158-160
-        Ml = Mp[c];
-        Dl = D;
+    auto second = [&](uint32_t &Bl, const uint32_t (&M)[CT], int c) {
+        const uint32_t D = Bl - gv;                                                  // :151-156 (no borrow)
+        A[c] = pk_max(M[c], A[c]);                          // A[c] was this row's I (:149-154); now max(M, I)
+        Bl = pk_max(M[c], D);
+        G[c] = pk_max(A[c], D);                                                      // :158-160
     };
 
     auto step = [&](const int t) {
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
         Z1 += gv; Z2 += gv;
-        // lane 0 of region 1 sits on the j = 0 border: M = H = 0 (the zero level), D = -INF
-        const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)M1, (int)Z1);
-        Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
+        // lane 0 of region 1 sits on the j = 0 border: the zero level
+        const uint32_t Bl1 = (uint32_t)dpp_row_shr1((int)B1, (int)Z1);
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
         // lane 0 of region 2 continues lane 15's region 1 (one step ago = same row, same zero level)
-        const uint32_t Ml2 = (uint32_t)dpp_row_shr1((int)M2, dpp_row_ror1((int)M1));
-        const uint32_t Dl2 = (uint32_t)dpp_row_shr1((int)D2, dpp_row_ror1((int)D1));
+        const uint32_t Bl2 = (uint32_t)dpp_row_shr1((int)B2, dpp_row_ror1((int)B1));
         const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)H1));
         uint32_t Hd = Hdiag1;
         Hdiag1 = Hl1;
+        uint32_t M[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            if (c < C1) { r1_first(Hd, c); continue; }
             if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb2b, rb2, qb[c]);
-            Hd = G[c];
-            I[c] = pk_max(Mp[c], I[c]);
-            Mp[c] = pk_max(Mx, Z2);
+            first(Hd, M, c, c < C1 ? rb1 : rb2, c < C1 ? rb1b : rb2b, c < C1 ? Z1 : Z2);
         }
-        uint32_t Ml = Ml1, Dl = Dl1;
+        uint32_t Bl = Bl1;
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            if (c == C1) {
-                M1 = Ml; D1 = Dl; H1 = G[C1 - 1];
-                Ml = Ml2; Dl = Dl2;
-            }
-            r1_second(Ml, Dl, c);
+            if (c == C1) { B1 = Bl; H1 = G[C1 - 1]; Bl = Bl2; }
+            second(Bl, M, c);
         }
-        M2 = Ml; D2 = Dl; H2 = G[CT - 1];
+        B2 = Bl; H2 = G[CT - 1];
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     };
 
-    // ---- pointer phase: region 2 on tagged scores.  Registers: G = 4H+3, Mp = 4M+3, I = 4I+2 (all drifted).
+    // ---- pointer phase: region 2 on tagged scores.  Registers: G = 4H+3, A = 4 max(M, I) + {3: M, 2: I}; the
+    //      lane-boundary B2 = 4 max(M, D) + {3: M, 1: D}
     uint32_t Z24 = 0;
     auto step_tagged = [&](const int t) {
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
         Z1 += gv; Z24 += g4v;
-        const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)M1, (int)Z1);
-        Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)Dl1);
+        const uint32_t Bl1 = (uint32_t)dpp_row_shr1((int)B1, (int)Z1);
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
-        // lane 15's region-1 column enters region 2: scaled and tagged like a region-2 column
-        const uint32_t Ml2 = (uint32_t)dpp_row_shr1((int)M2, dpp_row_ror1((int)pk_mad4(M1, kc.c3)));
-        const uint32_t Dl2 = (uint32_t)dpp_row_shr1((int)D2, dpp_row_ror1((int)pk_mad4(D1, kc.tag1)));
+        // lane 15's region-1 column enters region 2 scaled; which of M and D its B came from is not known, and
+        // not needed: the tag only feeds the flag of region 2's first column, eight columns left of the window
+        const uint32_t Bl2 = (uint32_t)dpp_row_shr1((int)B2, dpp_row_ror1((int)pk_mad4(B1, kc.c3)));
         const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4(H1, kc.c3)));
         uint32_t Hd = Hdiag1;
         Hdiag1 = Hl1;
+        uint32_t M[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            if (c < C1) { r1_first(Hd, c); continue; }
             if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb2b, rb2, qb[c]);            // 4(H[i-1][j-1] + sub) + 3
-            Hd = G[c];
-            I[c] = pk_max(Mp[c], I[c]);                      // low bits 3: ins_open >= ins_extend (:170), 2: not
-            Mp[c] = pk_max(Mx, Z24);                                                     // 4M + 3, M >= 0
+            first(Hd, M, c, c < C1 ? rb1 : rb2, c < C1 ? rb1b : rb2b, c < C1 ? Z1 : Z24);      // region 2: 4M + 3
         }
-        uint32_t Ml = Ml1, Dl = Dl1;
+        uint32_t Bl = Bl1;
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            if (c == C1) {
-                M1 = Ml; D1 = Dl; H1 = G[C1 - 1];
-                Ml = Ml2; Dl = Dl2;
-            }
-            if (c < C1) { r1_second(Ml, Dl, c); continue; }
-            const uint32_t Dp = pk_max(Ml, Dl);              // low bits 3: del_open >= del_extend (:171), 1: not
-            const uint32_t Dt = andn_or(Dp - g4v, c3v, t1v);
-            const uint32_t It = andn_or(I[c], c3v, t2v);
-            const uint32_t Hp = pk_max(pk_max(Mp[c], It), Dt);                           // :158-168
-            accF[c - C1] = pk_shl_add4(accF[c - C1], (I[c] ^ Dp) & c3v);
+            if (c == C1) { B1 = Bl; H1 = G[C1 - 1]; Bl = Bl2; }
+            if (c < C1) { second(Bl, M, c); continue; }
+            const uint32_t Dp = Bl - g4v;                    // low bits 3: del_open >= del_extend (:171), 1: not
+            const uint32_t Dt = andn_or(Dp, c3v, t1v);
+            const uint32_t It = andn_or(A[c], c3v, t2v);     // A[c]: low bits 3: ins_open >= ins_extend (:170), 2: not
+            accF[c - C1] = pk_shl_add4(accF[c - C1], (A[c] ^ Dp) & c3v);
+            A[c] = pk_max(M[c], It);
+            Bl = pk_max(M[c], Dt);
+            const uint32_t Hp = pk_max(A[c], Dt);                                        // :158-168
             accO[c - C1] = pk_shl_add4(accO[c - C1], Hp & c3v);
             G[c] = Hp | c3v;
-            I[c] = It;
-            Ml = Mp[c];
-            Dl = Dt;
         }
-        M2 = Ml; D2 = Dl; H2 = G[CT - 1];
+        B2 = Bl; H2 = G[CT - 1];
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8);
     };
     auto enter_tagged = [&]() {
 #pragma unroll
         for (int c = C1; c < CT; c++) {
             G[c] = pk_mad4(G[c], kc.c3);
-            Mp[c] = pk_mad4(Mp[c], kc.c3);
-            I[c] = pk_mad4(I[c], kc.tag2);
+            A[c] = pk_mad4(A[c], kc.c3);        // which of M and I it was is only asked for rows above the window
         }
-        M2 = pk_mad4(M2, kc.c3);
-        D2 = pk_mad4(D2, kc.tag1);
+        B2 = pk_mad4(B2, kc.c3);
         H2 = pk_mad4(H2, kc.c3);
         Hdiag2 = pk_mad4(Hdiag2, kc.c3);
         Z24 = pk_mad4(Z2, kc.c3);
@@ -278,15 +260,14 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
     const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), t1v = vconst(kc.tag1),
                    t2v = vconst(kc.tag2);
-    constexpr uint32_t kLow = 0;                 // stands for -INF (see dp_pass_lin_split)
     uint32_t Z = pk2(lin_base(g) + gl * g);      // zero level of the row this lane did "before step 1"
-    uint32_t G[C], Mp[C], I[C];
+    uint32_t G[C], A[C];                         // H and max(M, I) of the previous row (see dp_pass_lin_split)
     uint32_t accO[QD * 4], accF[QD * 4];
 #pragma unroll
-    for (int c = 0; c < C; c++) { G[c] = Z; Mp[c] = Z; I[c] = kLow; }
+    for (int c = 0; c < C; c++) { G[c] = Z; A[c] = Z; }
 #pragma unroll
     for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
-    uint32_t M_last = Z, D_last = kLow, G_last = Z, Hdiag = Z, Dl0 = kLow;
+    uint32_t B_last = Z, G_last = Z, Hdiag = Z;
 
     // arg-max state (see dp_pass_p16)
     uint32_t bk[AMAX ? C : 1];
@@ -314,27 +295,26 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     auto step = [&](const int t) {
         const uint32_t w_next = ref16[t + 1];
         Z += gv;
-        const uint32_t Ml0 = shr1(M_last, Z);
-        Dl0 = shr1(D_last, Dl0);
+        const uint32_t Bl0 = shr1(B_last, Z);            // j = 0 border: the zero level
         const uint32_t Hl = shr1(G_last, Z);
         uint32_t Hd = Hdiag;
         Hdiag = Hl;
+        uint32_t M[C];
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
             Hd = G[c];
-            I[c] = pk_max(Mp[c], I[c]);
-            Mp[c] = pk_max(Mx, Z);
+            M[c] = pk_max(Mx, Z);
         }
-        uint32_t Ml = Ml0, Dl = Dl0;
+        uint32_t Bl = Bl0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t D = pk_max(Ml, Dl) - gv;
-            G[c] = pk_max(pk_max(Mp[c], I[c]), D);
-            Ml = Mp[c];
-            Dl = D;
+            const uint32_t D = Bl - gv;
+            A[c] = pk_max(M[c], A[c]);
+            Bl = pk_max(M[c], D);
+            G[c] = pk_max(A[c], D);
         }
-        M_last = Ml; D_last = Dl; G_last = G[C - 1];
+        B_last = Bl; G_last = G[C - 1];
         lutA = lut(w_next & 0xffu); lutB = lut(w_next >> 8);
     };
 
@@ -350,50 +330,45 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
             const uint32_t kb = row0 < (uint32_t)rows[1] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
             key_c = pk_sub(ka | (kb << 16), Z8);
         }
-        const uint32_t Ml0 = shr1(M_last, Z4);
-        Dl0 = shr1(D_last, Dl0);
+        const uint32_t Bl0 = shr1(B_last, Z4);
         const uint32_t Hl = shr1(G_last, Z4);
         uint32_t Hd = Hdiag;
         Hdiag = Hl;
+        uint32_t M[C];
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
             Hd = G[c];
-            I[c] = pk_max(Mp[c], I[c]);
-            Mp[c] = pk_max(Mx, Z4);
+            M[c] = pk_max(Mx, Z4);
         }
-        uint32_t Ml = Ml0, Dl = Dl0;
+        uint32_t Bl = Bl0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t Dp = pk_max(Ml, Dl);
-            const uint32_t Dt = andn_or(Dp - g4v, c3v, t1v);
-            const uint32_t It = andn_or(I[c], c3v, t2v);
-            const uint32_t Hp = pk_max(pk_max(Mp[c], It), Dt);
-            accF[c] = pk_shl_add4(accF[c], (I[c] ^ Dp) & c3v);
+            const uint32_t Dp = Bl - g4v;
+            const uint32_t Dt = andn_or(Dp, c3v, t1v);
+            const uint32_t It = andn_or(A[c], c3v, t2v);
+            accF[c] = pk_shl_add4(accF[c], (A[c] ^ Dp) & c3v);
+            A[c] = pk_max(M[c], It);
+            Bl = pk_max(M[c], Dt);
+            const uint32_t Hp = pk_max(A[c], Dt);
             accO[c] = pk_shl_add4(accO[c], Hp & c3v);
             G[c] = Hp | c3v;
             if (AMAX) bk[c] = pk_max(bk[c], pk_mad_vvv(G[c], kc.tag2, key_c));      // 2 G'' + (step & 7) - 2 Z''
-            I[c] = It;
-            Ml = Mp[c];
-            Dl = Dt;
         }
-        M_last = Ml; D_last = Dl; G_last = G[C - 1];
+        B_last = Bl; G_last = G[C - 1];
         lutA = lut4(w_next & 0xffu); lutB = lut4(w_next >> 8);
     };
     auto enter_tagged = [&]() {
 #pragma unroll
         for (int c = 0; c < C; c++) {
             G[c] = pk_mad4(G[c], kc.c3);
-            Mp[c] = pk_mad4(Mp[c], kc.c3);
-            I[c] = pk_mad4(I[c], kc.tag2);
+            A[c] = pk_mad4(A[c], kc.c3);
         }
-        M_last = pk_mad4(M_last, kc.c3);
-        D_last = pk_mad4(D_last, kc.tag1);
-        Dl0 = pk_mad4(Dl0, kc.tag1);
+        B_last = pk_mad4(B_last, kc.c3);
         G_last = pk_mad4(G_last, kc.c3);
         Hdiag = pk_mad4(Hdiag, kc.c3);
         Z4 = pk_mad4(Z, kc.c3);
-        Z8 = pk_add(Z4, Z4);
+        Z8 = Z4 + Z4;
         lutA <<= 2; lutB <<= 2;
     };
 

@@ -174,6 +174,7 @@ struct gact_hip_engine {
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
+    int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
     gact::P16Consts kc;
     hipDeviceProp_t prop;
     int grid_blocks = 0;        // persistent grid
@@ -359,7 +360,8 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : 2;
         const int wide_cap = std::min(e->grid_blocks, per_cu * e->prop.multiProcessorCount);
         const int wide_blocks = std::max(1, std::min((n + 15) / 16, wide_cap));             // 4 tiles per wave
-        hipLaunchKernelGGL(km, dim3(sl.wide ? wide_blocks : main_blocks), dim3(gact::kBlockThreads), 0, sl.stream, kp,
+        const int lin_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->lin_grid_blocks));
+        hipLaunchKernelGGL(km, dim3(sl.wide ? wide_blocks : (sl.lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, sl.stream, kp,
                            e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file, sl.overlaps.p,
                            queues(sl), sl.d_ws);
         HIP_TRY(hipGetLastError());
@@ -375,8 +377,8 @@ template <int C> int occupancy_blocks(int *out)
     int m = std::min(a, b);
     for (int v = 0; v < 14; v++) {
         int c = m;
-        auto k = v == 12 ? gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>
-               : v == 13 ? gact::extend_p16_kernel<gact::WideLayoutLin, false>
+        if (v == 12) continue;          // the linear-gap split launch has its own grid (lin_occupancy_blocks)
+        auto k = v == 13 ? gact::extend_p16_kernel<gact::WideLayoutLin, false>
                : v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
                : v == 1 ? gact::extend_p16_kernel<gact::UniformLayout<C>, false>
                : v == 2 ? gact::extend_p16_kernel<gact::SplitLayout<7, 13>, true>
@@ -393,6 +395,15 @@ template <int C> int occupancy_blocks(int *out)
         m = std::min(m, c);
     }
     *out = std::max(1, m);
+    return 0;
+}
+
+int lin_occupancy_blocks(int *out)
+{
+    int a = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>,
+                                                         gact::kBlockThreads, 0));
+    *out = std::max(1, a);
     return 0;
 }
 
@@ -534,7 +545,12 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         // the workspace is sized for grid_blocks groups
         e->seed_grid_blocks = std::min(sb * e->prop.multiProcessorCount, e->grid_blocks);
     }
-    const size_t groups = (size_t)e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
+    {
+        int lb = 0;
+        if ((rc = lin_occupancy_blocks(&lb))) { delete e; return rc; }
+        e->lin_grid_blocks = std::max(e->grid_blocks, lb * e->prop.multiProcessorCount);
+    }
+    const size_t groups = (size_t)std::max(e->grid_blocks, e->lin_grid_blocks) * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
     e->ws_words_total = groups * gact::kSlots * (size_t)e->kp.ws_words;    // two tiles per group in the p16 kernel
 
     e->slots.resize(p->n_slots);

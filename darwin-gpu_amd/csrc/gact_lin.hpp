@@ -479,7 +479,11 @@ struct WideLayoutLin : UniformLayout<10, 32, true> {
 };
 
 // Layout policy for extend_p16_kernel: SplitLayout's column map, the linear-gap pass, FMT 3 pointer words
+#ifndef GACT_LIN_BLOCKS_PER_CU
+#define GACT_LIN_BLOCKS_PER_CU 3
+#endif
 template <int C1, int C2> struct SplitLayoutLin : SplitLayout<C1, C2, true> {
+    static constexpr int kBlocksPerCu = GACT_LIN_BLOCKS_PER_CU;
     static constexpr int kWalkFmt = 3;
     static constexpr bool kEndAligned = true;       // every tile's last row on the wave's last step
     template <bool RAW>

@@ -94,6 +94,11 @@ gact_hip_engine *side_engine(int tile, int overlap, int match, int mismatch, int
     p.first_tile_score_threshold = thr; p.device_id = shim_device(); p.n_slots = 1;
     gact_hip_engine *e = nullptr;
     SAFE(gact_hip_create(&p, &e));
+    if (g_side.empty())
+        atexit([] {                                  // the reference's CPU entry points have no close call to hang this on
+            for (auto &kv : g_side) gact_hip_destroy(kv.second);
+            g_side.clear();
+        });
     g_side[k] = e;
     return e;
 }

@@ -17,7 +17,8 @@ orc = oracle_py.Oracle()
 FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
 MODES = [{}, {"GACT_HIP_FORCE_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_TAGGED": "1"},
          {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_UNIFORM": "1"},
-         {"GACT_HIP_FORCE_INT32_SEED": "1"}, {"GACT_HIP_FORCE_INT32": "1"}]
+         {"GACT_HIP_FORCE_INT32_SEED": "1"}, {"GACT_HIP_FORCE_INT32": "1"},
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_LIN": "1"}, {"GACT_HIP_FORCE_WIDE": "1", "GACT_HIP_NO_LIN": "1"}]
 ALL = sorted({k for m in MODES for k in m})
 t0 = time.time()
 total = 0
@@ -30,6 +31,9 @@ for it in range(n_cfg):
     thr = int(rng.integers(1, 70))
     match = int(rng.integers(1, 7))
     scoring = (match, -int(rng.integers(0, 8)), -int(rng.integers(0, 12)), -int(rng.integers(0, 6)))
+    if rng.random() < 0.5:                       # linear gaps (open == extend == mismatch): the drifted pass
+        g = -int(rng.choice([0, 1, 1, 1, 2, 3, 5, 9]))
+        scoring = (match, g, g, g)
     n_frac = float(rng.choice([0.0, 0.0, 0.004]))
     rs = synth.simulate_reads(int(rng.integers(6000, 20000)), n_reads=int(rng.integers(6, 16)), seed=int(rng.integers(1 << 30)),
                               mean_len=int(rng.integers(1500, 5000)), sd_len=900, min_len=200, max_len=9000, n_frac=n_frac)
@@ -55,7 +59,7 @@ for it in range(n_cfg):
                 continue
             got = eng.extend(cands, complement=comp, same_file=True)
             st = eng.last_run_stats()
-            key = st["layout"] + "/" + st["seed_layout"]
+            key = st["layout"] + ("-lin" if st["linear_gap"] else "") + "/" + st["seed_layout"]
             layouts[key] = layouts.get(key, 0) + 1
             for f in FIELDS:
                 if not np.array_equal(got[f], want[comp][f]):

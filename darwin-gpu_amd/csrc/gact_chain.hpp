@@ -204,37 +204,20 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     int nis = 0, njs = 0;                                       // minus the ref / query steps taken
     int n_ext = 0, n_open = 0, n_eq = 0, n_m = 0;
     uint32_t cur = 0, fl = 0;                                   // state (op-code numbering), flags of the current cell
-    // FMT 3 walks refill their region cache every 16 steps (tb_refill16_at), the others every 8
-    constexpr int kSpan = FMT == 3 ? 16 : 8;
     TbRegion<CW> rg;
-    TbRegion16<CW> rg16;
-    int off0 = 0, off1 = 0, off2 = 0;                           // byte offsets inside the region cache
+    int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
-        if (kSpan == 16) {
-            tb_refill16_at<CW, QN, LANES>(ws, scratch, l, c, k, rg16);
-            rg.l0 = rg16.l0; off0 = rg16.off[0]; off1 = rg16.off[1]; off2 = rg16.off[2];
-        } else {
-            tb_refill_at<CW, QN, LANES>(ws, scratch, l, c, k, rg);
-            off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
-            off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
-        }
+        tb_refill_at<CW, QN, LANES>(ws, scratch, l, c, k, rg);
+        off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
+        off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
     };
     // 32-bit LDS addressing (through the generic pointer the index arithmetic is done in 64 bits)
     typedef __attribute__((address_space(3))) const uint8_t LdsByte;
     typedef __attribute__((address_space(3))) const uint32_t LdsWord;
     LdsByte *cache = (LdsByte *)scratch;
     auto fetch = [&](int l, int c, int k, uint32_t &code, uint32_t &flags) {
-        uint32_t at;
-        if (kSpan == 16) {
-            // 48 * quad index + 16 * (block - first cached block of the lane) + 4 * (c & 3), see tb_refill16_at
-            const int li = rg.l0 - l;
-            const int off = li == 0 ? off0 : (li == 1 ? off1 : off2);
-            const int a = 4 * c - 64 * (c >> 2) + 16 * (int)((uint32_t)k >> 3) + off;
-            at = (uint32_t)imin(imax(a, 0), 4 * (kTbScratchWords16 - 1));    // a walker about to stop may point anywhere
-        } else {
-            at = (uint32_t)(4 * c + (int)__umul24((uint32_t)k >> 3, 48u) + (l == rg.l0 ? off0 : off1));
-        }
+        const uint32_t at = (uint32_t)(4 * c + (int)__umul24((uint32_t)k >> 3, 48u) + (l == rg.l0 ? off0 : off1));
         const uint32_t w = *(LdsWord *)(cache + at);
         if (FMT == 1) {
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
@@ -295,7 +278,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
         const int c = p + __mul24(l, -CW);
         const int k = imax(kA + l + nis, 0);
-        if ((it & (kSpan - 1)) == kSpan - 1) refill(l, c, k);
+        if ((it & 7) == 7) refill(l, c, k);
         uint32_t code;
         fetch(l, c, k, code, fl);
         if (FMT == 3) code = (v == 0) ? 0u : code;               // only looked at after a diagonal move

@@ -440,8 +440,7 @@ __device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int 
 // 12 uint4) from the HBM workspace into its own LDS scratch -- all 12 loads in
 // flight at once, one latency per 8 steps -- and the steps in between read LDS.
 constexpr int kTbSpan = 8;
-constexpr int kTbScratchWords = 12 * 4;      // dwords of LDS per walker: 12 uint4 for 8-step regions ...
-constexpr int kTbScratchWords16 = 21 * 4;    // ... 21 for 16-step ones (tb_refill16_at)
+constexpr int kTbScratchWords = 12 * 4;      // dwords of LDS per walker
 
 template <int CW> struct TbRegion {
     int l0;              // lane of the anchor column
@@ -489,62 +488,6 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
     u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
 #pragma unroll
     for (int n = 0; n < 12; n++) dst[n] = r[n];
-}
-
-// The same with regions of 16 steps (rows i-16..i, columns j-16..j): half the memory round trips per walk.
-// 17 columns are at most 7 column quads, counted backwards from the anchor's quad across up to three lanes
-// (lane l0 - 1 continues with its last quad after lane l0's first), times three flush blocks = 21 uint4, all in
-// flight at once.  Cache layout [quad index 0..6][block 0..2][4 words]; the quad index of (lane, column) is
-// (q0 - (c >> 2)) + QN * (l0 - lane), the first cached block of a lane follows its own stored-step offset.
-template <int CW> struct TbRegion16 {
-    int l0;              // lane of the anchor column
-    int off[3];          // byte offset of the cache address, by lane distance 0..2 (see tb_fetch_addr16)
-};
-
-template <int CW, int QN, int LANES = kGroup>
-__device__ __forceinline__ void tb_refill16_at(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
-                                               TbRegion16<CW> &rg)
-{
-    static_assert(QN >= 2 && QN <= 8, "column quads per lane");
-    rg.l0 = l0;
-    const int q0 = c0 >> 2;
-    int fb[3];
-#pragma unroll
-    for (int li = 0; li < 3; li++) {
-        fb[li] = imax(((k0 - li) >> 3) - 2, 0);          // the same row sits li stored steps earlier li lanes to the left
-        rg.off[li] = 48 * QN * li - 16 * fb[li] + 48 * q0;
-    }
-    const u32x4 *base = reinterpret_cast<const u32x4 *>(ws);
-    const u32x4 *addr[21];
-#pragma unroll
-    for (int idx = 0; idx < 7; idx++) {
-        const int lin = imax(l0 * QN + q0 - idx, 0);     // (lane, quad) as one number, counted backwards
-        const int lane = (int)(__umul24((uint32_t)lin, (65536u + QN - 1) / QN) >> 16);
-        const int quad = lin - lane * QN;
-        const int li = imin(l0 - lane, 2);
-        const int fbl = li == 0 ? fb[0] : (li == 1 ? fb[1] : fb[2]);
-#pragma unroll
-        for (int b = 0; b < 3; b++) addr[idx * 3 + b] = base + ((fbl + b) * QN + quad) * LANES + lane;
-    }
-    u32x4 r[21];
-#pragma unroll
-    for (int g = 0; g < 5; g++)
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                     "global_load_dwordx4 %1, %5, off sc1\n\t"
-                     "global_load_dwordx4 %2, %6, off sc1\n\t"
-                     "global_load_dwordx4 %3, %7, off sc1"
-                     : "=&v"(r[4 * g]), "=&v"(r[4 * g + 1]), "=&v"(r[4 * g + 2]), "=&v"(r[4 * g + 3])
-                     : "v"(addr[4 * g]), "v"(addr[4 * g + 1]), "v"(addr[4 * g + 2]), "v"(addr[4 * g + 3])
-                     : "memory");
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(r[20]) : "v"(addr[20]) : "memory");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
-                   "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]),
-                   "+v"(r[16]), "+v"(r[17]), "+v"(r[18]), "+v"(r[19]), "+v"(r[20])
-                 :: "memory");
-    u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
-#pragma unroll
-    for (int n = 0; n < 21; n++) dst[n] = r[n];
 }
 
 // Pointer word formats (read by walk_chain, gact_chain.hpp):

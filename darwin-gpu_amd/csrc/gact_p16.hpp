@@ -744,7 +744,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsOfWave;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
-    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][L::kWalkFmt == 3 ? kTbScratchWords16 : kTbScratchWords];
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
     __shared__ uint32_t stage_lds[kGroupsPerBlock][StageGeom<L::kSlotsPerLane, LANES>::kWords];
 
     WaveCtx w;
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
     constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
-    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][LIN ? kTbScratchWords16 : kTbScratchWords];
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
     __shared__ uint32_t stage_lds[kGroupsPerBlock][StageGeom<C, kGroup>::kWords];
 
     const WaveCtx w = wave_ctx();

@@ -189,7 +189,7 @@ struct ScoreWalk {
 // takes the move's own score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE
 // step the gap score (open == extend here); after a diagonal move v is H of the new cell, and ZERO means v == 0
 // (align.cpp:166-168: M <= 0, I <= 0 and D <= 0, i.e. H == 0).
-template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup>
+template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup, bool COMPACT = false>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
@@ -208,7 +208,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
-        tb_refill_at<CW, QN, LANES>(ws, scratch, l, c, k, rg);
+        tb_refill_at<CW, QN, LANES, COMPACT>(ws, scratch, l, c, k, rg);
         off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
     };

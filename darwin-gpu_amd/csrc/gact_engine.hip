@@ -118,6 +118,10 @@ struct Slot {
     int *d_flags = nullptr;
     gact_overlap *h_records = nullptr;  // pinned staging for candidates_fetch (pageable D2H is staged by the runtime
     size_t h_records_cap = 0;           // in small chunks: 0.2-0.9 ms for 3.7 MB; pinned + memcpy: 0.25 ms)
+    // a caller that fetches into the same buffer again and again (a feeder thread's result array) gets it
+    // page-locked the second time it is seen: the records then go straight there, no staging copy
+    void *last_out = nullptr, *reg_out = nullptr;
+    size_t reg_bytes = 0;
     SeqSet inline_ref, inline_query;   // Align_Batch_GPU-style inline tiles
 };
 
@@ -562,7 +566,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
             hipEventCreate(&sl.ev_mid) != hipSuccess ||
             hipMalloc((void **)&sl.d_counter, kCounterInts * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&sl.d_flags, sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&sl.d_ws, e->ws_words_total * sizeof(uint32_t)) != hipSuccess) {
+            hipMalloc((void **)&sl.d_ws, (e->ws_words_total + 64) * sizeof(uint32_t)) != hipSuccess) {     // + slack: a walker's
+                                                                        // uint4 load of a compact last column reads 12 bytes past it
             gact_hip_destroy(e);
             return fail(GACT_HIP_ENOMEM, "slot allocation failed (workspace %zu MiB per slot)",
                         e->ws_words_total * 4 >> 20);
@@ -585,6 +590,7 @@ void gact_hip_destroy(gact_hip_engine *e)
         if (sl.d_flags) (void)hipFree(sl.d_flags);
         if (sl.d_ws) (void)hipFree(sl.d_ws);
         if (sl.h_records) (void)hipHostFree(sl.h_records);
+        if (sl.reg_out) { (void)hipHostUnregister(sl.reg_out); (void)hipGetLastError(); }
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
         if (sl.ev1) (void)hipEventDestroy(sl.ev1);
         if (sl.ev_mid) (void)hipEventDestroy(sl.ev_mid);
@@ -820,6 +826,18 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
     if (n < 0 || (size_t)n > sl.n_cands || (n > 0 && !out))
         return fail(GACT_HIP_EINVAL, "candidates_fetch: bad arguments (slot %d holds %zu candidates)", slot, sl.n_cands);
     if ((rc = set_device(e))) return rc;
+    const size_t bytes = (size_t)n * sizeof(gact_overlap);
+    if (n > 0 && out == sl.last_out && (sl.reg_out != out || sl.reg_bytes < bytes)) {
+        if (sl.reg_out) { (void)hipHostUnregister(sl.reg_out); sl.reg_out = nullptr; sl.reg_bytes = 0; }
+        if (hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess) { sl.reg_out = out; sl.reg_bytes = bytes; }
+        else (void)hipGetLastError();
+    }
+    sl.last_out = out;
+    if (n > 0 && sl.reg_out == out && sl.reg_bytes >= bytes) {
+        HIP_TRY(hipMemcpyAsync(out, sl.overlaps.p, bytes, hipMemcpyDeviceToHost, sl.stream));
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+        return 0;
+    }
     if ((size_t)n > sl.h_records_cap) {
         if (sl.h_records) (void)hipHostFree(sl.h_records);
         sl.h_records = nullptr; sl.h_records_cap = 0;

@@ -205,35 +205,39 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     for (; t < tB && t <= T_end; t++) step(t);
     const bool tagged = t <= T_end;
     if (tagged) enter_tagged();
+    // flush block layout: WsBlock (gact_device.hpp), compact when the last column quad holds one column (C2 = 13)
+    constexpr bool COMPACT = (C2 % 4) == 1;
+    constexpr int QF = COMPACT ? QD - 1 : QD;                  // full quads
+    constexpr int kBlockU4 = WsBlock<QD, kGroup, COMPACT>::kUint4;
     uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
     uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
+    auto flush = [&](auto fix) {
+#pragma unroll
+        for (int q = 0; q < QF; q++) {
+            qA[q * kGroup] = make_uint4(fix(wordA(accO[4 * q], accF[4 * q])), fix(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+                                        fix(wordA(accO[4 * q + 2], accF[4 * q + 2])), fix(wordA(accO[4 * q + 3], accF[4 * q + 3])));
+            qB[q * kGroup] = make_uint4(fix(wordB(accO[4 * q], accF[4 * q])), fix(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+                                        fix(wordB(accO[4 * q + 2], accF[4 * q + 2])), fix(wordB(accO[4 * q + 3], accF[4 * q + 3])));
+        }
+        if (COMPACT) {          // the last column: one dword per lane behind the full quads
+            reinterpret_cast<uint32_t *>(qA - gl + QF * kGroup)[gl] = fix(wordA(accO[4 * QF], accF[4 * QF]));
+            reinterpret_cast<uint32_t *>(qB - gl + QF * kGroup)[gl] = fix(wordB(accO[4 * QF], accF[4 * QF]));
+        }
+    };
     // whole blocks of eight steps, each followed by its flush (an `if ((k & 7) == 7)` inside one loop is
     // if-converted by the compiler: the 26 re-pairing v_perm of the flush would then run at every step)
     int k = 0;
     while (t + 7 <= T_end) {
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
-#pragma unroll
-        for (int q = 0; q < QD; q++) {
-            qA[q * kGroup] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
-                                        wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
-            qB[q * kGroup] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
-                                        wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
-        }
-        qA += QD * kGroup;
-        qB += QD * kGroup;
+        flush([](uint32_t w) { return w; });
+        qA += kBlockU4;
+        qB += kBlockU4;
     }
     for (; t <= T_end; t++, k++) step_tagged(t);
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
-        auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
-#pragma unroll
-        for (int q = 0; q < QD; q++) {
-            qA[q * kGroup] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
-                                        just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
-            qB[q * kGroup] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
-                                        just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
-        }
+        flush([sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); });
     }
     // H of the last column at the row of the last step, drift taken off
     return tagged ? pk_ashr2(pk_sub(H2, Z24)) : pk_sub(H2, Z2);
@@ -486,6 +490,7 @@ template <int C1, int C2> struct SplitLayoutLin : SplitLayout<C1, C2, true> {
     static constexpr int kBlocksPerCu = GACT_LIN_BLOCKS_PER_CU;
     static constexpr int kWalkFmt = 3;
     static constexpr bool kEndAligned = true;       // every tile's last row on the wave's last step
+    static constexpr bool kWalkCompact = (C2 % 4) == 1;
     template <bool RAW>
     __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
                                     int T_end, int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &pt)

@@ -190,6 +190,9 @@ int gact_hip_extend_candidates(gact_hip_engine *e, int slot, int32_t n,
  * the inputs already resident in HBM */
 int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const gact_candidate *cands);
 int gact_hip_candidates_run(gact_hip_engine *e, int slot, int32_t n, int complement, int same_file);
+/* fetch: records [0, n) into the caller's buffer.  A buffer that is passed twice in a row is page-locked by the
+ * engine (hipHostRegister) so that later fetches go straight into it; it stays registered until another buffer is
+ * passed or the engine is destroyed -- keep it alive that long. */
 int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_overlap *out);
 /* runs on candidates [first, first+n) of the uploaded array (multi-GPU shards) */
 int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n,

@@ -163,7 +163,8 @@ def main():
     if use_dist:
         # the one collective of the path: gather of fixed-size overlap records to rank 0, straight from
         # the engine's device-resident record array (no host round trip in front of RCCL)
-        gather = gdist.RecordGather(torch, dist, nf + nr, engine.OVERLAP_DTYPE.itemsize, rank, world, "cuda")
+        # (32 bytes per record travel: the eight numbers of an output line; dist.LINE_DTYPE)
+        gather = gdist.RecordGather(torch, dist, nf + nr, gdist.LINE_BYTES, rank, world, "cuda")
         dev_rec = gdist.DeviceRecords(eng.device_overlaps_ptr(0), nf + nr, engine.OVERLAP_DTYPE.itemsize)
 
     def step(record_ms=False):
@@ -173,8 +174,8 @@ def main():
             eng.sync(0)                                  # the engine's own stream: records complete in HBM
             parts = gather(dev_rec)
             if rank == 0:
-                gathered = gather.to_host(parts, engine.OVERLAP_DTYPE)      # the job's output, on the host
-            rec = gathered[0] if rank == 0 else None
+                gathered = gather.to_host(parts, gdist.LINE_DTYPE)          # the job's output, on the host
+            rec = None
         else:
             rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
         if record_ms:
@@ -189,8 +190,12 @@ def main():
         rec, gathered = step(record_ms=True)
     barrier()
     dt = time.perf_counter() - t0
-    if rec is None:                                      # ranks other than 0 only need their records for the cell count
+    if rec is None:          # distributed run: the engine's full records of this rank, for the cell count and the parity gate
         rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
+        if gathered is not None:                         # what rank 0 gathered of itself is what its engine holds
+            mine = gdist.lines_from_overlaps(rec)
+            if gathered[0].tobytes() != mine.tobytes():
+                raise SystemExit("bench.py: gathered records differ from the engine's")
     rf, rr = rec[:nf], rec[nf:]
 
     my_cells = int(rf["cells"].sum() + rr["cells"].sum())

@@ -88,6 +88,29 @@ class DeviceRecords:
                                          "version": 2, "strides": None}
 
 
+# What travels in the gather: the eight numbers of an output line (gact.cpp:214-224), 32 bytes, with the engine's
+# `emitted` flag (gact.cpp:213: is the line printed at all) folded into bit 1 of `comp`.  The engine's own record
+# (gact_overlap, 56 bytes) carries bookkeeping (first-tile score, tile and cell counts) that rank 0 has no use for.
+LINE_DTYPE = np.dtype([(n, "<i4") for n in ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp_emitted")])
+LINE_BYTES = 32
+
+
+def line_records(torch, src):
+    """(n, 56) uint8 device tensor of gact_overlap records -> (n, 32) uint8 tensor of LINE_DTYPE records"""
+    out = src[:, :LINE_BYTES].clone()
+    out[:, 28] |= (src[:, 32] != 0).to(torch.uint8) << 1
+    return out
+
+
+def lines_from_overlaps(records):
+    """the same on the host (CPU tests, single-process runs)"""
+    out = np.zeros(len(records), dtype=LINE_DTYPE)
+    for n in ("ref_id", "query_id", "ab", "ae", "bb", "be", "score"):
+        out[n] = records[n]
+    out["comp_emitted"] = records["comp"] | ((records["emitted"] != 0).astype(np.int32) << 1)
+    return out
+
+
 class RecordGather:
     """The one collective of the path: rank 0 receives every rank's overlap records.  The record counts
     are fixed once the candidates are dealt, so they are exchanged once; every step after that is one padded
@@ -109,6 +132,8 @@ class RecordGather:
         torch = self.torch
         if isinstance(records, DeviceRecords):
             src = torch.as_tensor(records, device=self.device)
+            if self.itemsize == LINE_BYTES and src.shape[1] != LINE_BYTES:
+                src = line_records(torch, src)           # engine records narrowed to the printable line, on the device
         else:
             src = torch.from_numpy(np.ascontiguousarray(records).view(np.uint8).reshape(-1, self.itemsize)).to(self.device)
         if self.n_mine:

@@ -65,12 +65,16 @@ eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); 
 n = len(cf) + len(cr)
 eng.candidates_upload(np.concatenate([cf, cr]))
 g = gdist.RecordGather(torch, dist, n, engine.OVERLAP_DTYPE.itemsize, 0, 1, "cuda")
+gl = gdist.RecordGather(torch, dist, n, gdist.LINE_BYTES, 0, 1, "cuda")          # what bench.py gathers: 32-byte lines
 dev = gdist.DeviceRecords(eng.device_overlaps_ptr(0), n, engine.OVERLAP_DTYPE.itemsize)
 for _ in range(3):
     eng.candidates_run_mixed(n, rc_from=len(cf)); eng.sync(0)
     got = g.to_host(g(dev), engine.OVERLAP_DTYPE)[0]
+    lines = gl.to_host(gl(dev), gdist.LINE_DTYPE)[0]
     want = eng.candidates_fetch(n)
     assert got.tobytes() == want.tobytes() and want["n_tiles"].sum() > n
+    assert lines.tobytes() == gdist.lines_from_overlaps(want).tobytes()
+    assert ((lines["comp_emitted"] >> 1) == want["emitted"]).all() and want["emitted"].sum() > 0
 host = gdist.gather_records(torch, dist, want, 0, 1, "cuda")[0]
 assert host.tobytes() == want.tobytes()
 eng.close()

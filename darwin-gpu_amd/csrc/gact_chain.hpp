@@ -236,8 +236,10 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     };
 
     int v = v0;                                                 // FMT 3: H of the current cell
-    const int s_gap = __builtin_amdgcn_readfirstlane(kp.ext), s_dm = __builtin_amdgcn_readfirstlane(kp.mismatch - kp.ext),
-              s_de = __builtin_amdgcn_readfirstlane(kp.match - kp.mismatch);
+    int v_gap, v_mism, v_match;                                 // the three column scores, in VGPRs (see the loop)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v_gap) : "s"(__builtin_amdgcn_readfirstlane(kp.ext)));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v_mism) : "s"(__builtin_amdgcn_readfirstlane(kp.mismatch)));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v_match) : "s"(__builtin_amdgcn_readfirstlane(kp.match)));
     if (R >= 1 && Q >= 1 && early > 0) {
         refill(l0, c0, k0);
         fetch(l0, c0, k0, cur, fl);
@@ -255,17 +257,19 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209)
         const uint64_t g = lanes(cur != kM);
         const uint64_t eq = lanes(ra[nis * rstride] == qa[njs]);
-        n_ext = add_lane_bit(n_ext, gprev & g);
-        n_open = add_lane_bit(n_open, (gprev ^ g) & ((left_m & gprev) | (~left_m & g)));
-        n_m = add_lane_bit(n_m, ~g);
-        n_eq = add_lane_bit(n_eq, ~g & eq);
-        gprev = (gprev & ~lanes(true)) | g;                       // walkers that have stopped keep their last column
         if (FMT == 3) {
-            // (differences of scalars held in registers: a select between kp's fields themselves is turned into an
-            // indexed load from the kernel argument segment, one memory round trip per step)
-            int cost = add_lane_bit_scaled(s_gap, lanes(cur == kM), s_dm);        // gap, or mismatch for a MATCH step ...
-            cost = add_lane_bit_scaled(cost, eq & lanes(cur == kM), s_de);         // ... or match
-            v -= cost;
+            // the score of this column comes off v.  With gap_open == gap_extend that running sum is also all the
+            // rescoring of gact.cpp:197-210 needs: no event counters, no open / extend bookkeeping in this walk.
+            // (Scalars held in registers: a select between kp's fields themselves is turned into an indexed load
+            // from the kernel argument segment, one memory round trip per step.)
+            const int sub = select_lane_bit(eq, v_match, v_mism);
+            v -= select_lane_bit(g, v_gap, sub);
+        } else {
+            n_ext = add_lane_bit(n_ext, gprev & g);
+            n_open = add_lane_bit(n_open, (gprev ^ g) & ((left_m & gprev) | (~left_m & g)));
+            n_m = add_lane_bit(n_m, ~g);
+            n_eq = add_lane_bit(n_eq, ~g & eq);
+            gprev = (gprev & ~lanes(true)) | g;                   // walkers that have stopped keep their last column
         }
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
         nis = sub_lane_bit(nis, lanes(cur != kD));
@@ -285,7 +289,13 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         const uint32_t nxt = cur == kM ? code : forced;
         cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
     }
-    ref_steps = -nis; query_steps = -njs; nst = -nis - njs - n_m;
+    ref_steps = -nis; query_steps = -njs;
+    if (FMT == 3) {
+        nst = -nis - njs;                                        // only "were there any columns" is asked (chain_advance)
+        wk.score += v0 - v;                                      // what the columns of this tile scored
+        return;                                                  // open == extend: the gap bookkeeping of wk decides nothing
+    }
+    nst = -nis - njs - n_m;
     wk.score += n_ext * kp.ext + n_open * kp.open + n_eq * kp.match + (n_m - n_eq) * kp.mismatch;
     const bool last_gap = (gprev >> (threadIdx.x & 63)) & 1;
     wk.pend_gap = left ? (int)last_gap : wk.pend_gap;

@@ -183,12 +183,18 @@ struct ScoreWalk {
 // byte stride.  (l0, c0, k0) = lane, column-in-lane and stored step of the start cell
 // (R, Q) in the pass's layout; CW columns per lane, QN column quads stored per lane.
 //
-// FMT 3 (linear-gap pass, gact_lin.hpp): the pointer word does not say ZERO -- MATCH and ZERO share a code,
-// because H == 0 is the one case the tagged max cannot tell from M == H.  The walker knows it anyway: it
-// carries the score of the cell it stands on, v (H of the start cell comes from the pass: v0), and every move
-// takes the move's own score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE
-// step the gap score (open == extend here); after a diagonal move v is H of the new cell, and ZERO means v == 0
-// (align.cpp:166-168: M <= 0, I <= 0 and D <= 0, i.e. H == 0).
+// FMT 3 (linear-gap pass, gact_lin.hpp: gap_open == gap_extend == mismatch =: g): the pointer is the op code alone,
+// op = which of M, H_up + g, H_left + g made H (ties M, then I, then D -- the order of align.cpp:162-164).
+//   * No flags.  align.cpp:218-229 leaves INSERT at (i, j) for MATCH iff M[i-1][j] >= I[i-1][j].  The walk is in
+//     INSERT at (i, j) only when I[i][j] > M[i][j]; were D the strict maximum at (i-1, j), then
+//     I[i][j] < D[i-1][j] + g <= H[i-1][j-1] + 2g <= H[i-1][j-1] + mismatch <= M[i][j].  So the op of (i-1, j) is
+//     MATCH or INSERT there, and says exactly what the flag says; DELETE likewise with (i, j-1).  The next state is
+//     the op of the cell the walk enters, whatever the move.  (tools/lin_walk_model.py checks the rule against
+//     the oracle on random tiles; tests/test_gpu_chain.py the kernels.)
+//   * No ZERO: H == 0 is the one case the tagged max cannot tell from M == H.  The walker carries the score of the
+//     cell it stands on, v (H of the start cell comes from the pass: v0), and every move takes the move's own
+//     score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE step g; after a diagonal
+//     move v is H of the new cell, and ZERO means v == 0 (align.cpp:166-168: M <= 0, I <= 0, D <= 0, i.e. H == 0).
 template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup, bool COMPACT = false>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
@@ -208,6 +214,12 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
+        if (FMT == 3) {         // dword (c >> 1) + 8 * (k >> 3) of a lane's two cached blocks x two cached octets
+            tb_refill_oct<CW, QN, LANES>(ws, scratch, l, c, k, rg);
+            off0 = 4 * (-8 * rg.fbase[0] - 4 * rg.qbase0);
+            off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
+            return;
+        }
         tb_refill_at<CW, QN, LANES, COMPACT>(ws, scratch, l, c, k, rg);
         off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
@@ -217,13 +229,19 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     typedef __attribute__((address_space(3))) const uint32_t LdsWord;
     LdsByte *cache = (LdsByte *)scratch;
     auto fetch = [&](int l, int c, int k, uint32_t &code, uint32_t &flags) {
+        if (FMT == 3) {
+            const uint32_t at = (uint32_t)((2 * c & ~3) + (int)(((uint32_t)k >> 3) << 5) + (l == rg.l0 ? off0 : off1));
+            const uint32_t w = *(LdsWord *)(cache + at);
+            code = (w >> (((~(uint32_t)k & 7u) * 2u) | (((uint32_t)c & 1u) << 4))) & 3u;
+            return;
+        }
         const uint32_t at = (uint32_t)(4 * c + (int)__umul24((uint32_t)k >> 3, 48u) + (l == rg.l0 ? off0 : off1));
         const uint32_t w = *(LdsWord *)(cache + at);
         if (FMT == 1) {
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
-        } else if (FMT == 2 || FMT == 3) {                       // taken as it is: the walk runs on this numbering
+        } else if (FMT == 2) {                                   // taken as it is: the walk runs on this numbering
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
@@ -274,9 +292,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
         nis = sub_lane_bit(nis, lanes(cur != kD));
         njs = sub_lane_bit(njs, lanes(cur != kI));
-        // FMT 3 flags: bit 0 set = the insertion goes on, bit 1 set = the deletion goes on
-        const uint32_t forced = FMT == 3 ? ((fl & (cur ^ 3u)) ? cur : kM)
-                              : FMT == 2 ? ((fl & cur) ? kM : cur) : ((fl & (4u - cur)) ? cur : kM);
+        const uint32_t forced = FMT == 2 ? ((fl & cur) ? kM : cur) : ((fl & (4u - cur)) ? cur : kM);
         // (a walker that is about to stop may have left the tile: keep its addresses inside the stored window)
         const int p = imax(p0 + njs, 0);
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
@@ -285,8 +301,9 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         if ((it & 7) == 7) refill(l, c, k);
         uint32_t code;
         fetch(l, c, k, code, fl);
-        if (FMT == 3) code = (v == 0) ? 0u : code;               // only looked at after a diagonal move
-        const uint32_t nxt = cur == kM ? code : forced;
+        // FMT 3: the op of the cell just entered is the next state whatever the move was (see above); ZERO is
+        // only asked for after a diagonal move (align.cpp:211-212 against :219, :225)
+        const uint32_t nxt = FMT == 3 ? ((cur == kM && v == 0) ? 0u : code) : (cur == kM ? code : forced);
         cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
     }
     ref_steps = -nis; query_steps = -njs;

@@ -509,12 +509,57 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
     for (int n = 0; n < 12; n++) dst[n] = r[n];
 }
 
+// The same for the linear-gap pass's words (FMT 3, gact_lin.hpp: eight columns per uint4, QN uint4 per lane and
+// flush block): 2 lanes x 2 flush blocks x 2 column octets = 8 uint4.  Nine adjacent columns always lie in two
+// octets; lane l0-1 caches its last two.
+template <int CW, int QN, int LANES>
+__device__ __forceinline__ void tb_refill_oct(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
+                                              TbRegion<CW> &rg)
+{
+    static_assert(QN >= 2 && CW > 8, "two column octets per lane at least");
+    rg.l0 = l0;
+    rg.qbase0 = imax(c0 - kTbSpan, 0) >> 3;
+    const u32x4 *base = reinterpret_cast<const u32x4 *>(ws);
+    const u32x4 *addr[8];
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) {
+        const int k_anchor = k0 - sl;
+        const int fb = imax((k_anchor >> 3) - 1, 0);
+        rg.fbase[sl] = fb;
+        const int lane = imax(l0 - sl, 0);
+        const int ob = sl ? QN - 2 : rg.qbase0;
+#pragma unroll
+        for (int lev = 0; lev < 2; lev++)
+#pragma unroll
+            for (int oq = 0; oq < 2; oq++)
+                addr[(sl * 2 + lev) * 2 + oq] = ws_quad_addr<QN, LANES, false>(base, fb + lev, imin(ob + oq, QN - 1), lane);
+    }
+    u32x4 r[8];
+#pragma unroll
+    for (int g = 0; g < 2; g++)
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                     "global_load_dwordx4 %1, %5, off sc1\n\t"
+                     "global_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc1"
+                     : "=&v"(r[4 * g]), "=&v"(r[4 * g + 1]), "=&v"(r[4 * g + 2]), "=&v"(r[4 * g + 3])
+                     : "v"(addr[4 * g]), "v"(addr[4 * g + 1]), "v"(addr[4 * g + 2]), "v"(addr[4 * g + 3])
+                     : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 :: "memory");
+    u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
+#pragma unroll
+    for (int n = 0; n < 8; n++) dst[n] = r[n];
+}
+
 // Pointer word formats (read by walk_chain, gact_chain.hpp):
 // FMT 0: the int32 kernels' word, 8 rows x 4 bits {ins_open>=ins_extend, del_open>=del_extend, op}, first row on top.
 // FMT 1: the packed kernel's word, low half 8 rows x 2 bits op code (0 ZERO 1 MATCH 2 INSERT 3 DELETE),
 //        high half 8 rows x 2 bits {ins_open<ins_extend, del_open<del_extend}.
 // FMT 2: the tagged pass's word, low half 8 rows x 2 bits op in align.h:23 numbering (Z0 D1 I2 M3), high half
 //        8 rows x 2 bits {ins_open>=ins_extend, del_open>=del_extend}.
+// FMT 3: the linear-gap pass's word: two columns, each a half-word of 8 rows x 2 bits op (D1 I2 M3; ZERO is not
+//        encoded), nothing else -- see walk_chain.
 
 // ---------------------------------------------------------------------------
 // Loads one group's tile into LDS + registers.  DP index d (0-based) of a

@@ -70,6 +70,31 @@ __device__ __forceinline__ uint32_t pk_ashr2(uint32_t a)
     return r;
 }
 
+// Pointer words of this pass (walk_chain's FMT 3): two bits per cell, the op code alone.  A half-word holds eight
+// stored steps of one column (first step on top), a dword two adjacent columns (the even one low), a uint4 eight
+// columns; a flush block is [uint4 n][lane], n < kUint4 (WsBlock<kUint4, LANES, false>, gact_device.hpp).
+template <int CW> struct LinWords {
+    static constexpr int kWords = (CW + 1) / 2;          // dwords per lane, tile and flush
+    static constexpr int kUint4 = (kWords + 3) / 4;
+};
+// acc[c]: the codes of column c, tile A in the low half-word, tile B in the high one
+template <int NW, int LANES, class Fix>
+__device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *qA, uint4 *qB, Fix fix)
+{
+    constexpr int QD = (NW + 3) / 4;
+    uint32_t wa[QD * 4], wb[QD * 4];
+#pragma unroll
+    for (int n = 0; n < QD * 4; n++) {
+        wa[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x05040100u)) : 0u;
+        wb[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x07060302u)) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < QD; q++) {
+        qA[q * LANES] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
+        qB[q * LANES] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Split layout (see gact_p16s.hpp for the column map).  Returns, in lane 15 of every group, H[R][Q] of both tiles
 // (packed, plain scores) -- valid when every tile's last row is the wave's last step (shift = T_end - Tend).
@@ -81,22 +106,21 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
                                                       uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB)
 {
     constexpr int CT = C1 + C2;
-    constexpr int QD = (C2 + 3) / 4;
+    constexpr int NW = LinWords<C2>::kWords, QD = LinWords<C2>::kUint4;
     constexpr int LAG = kGroup;
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
-    const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), t1v = vconst(kc.tag1),
-                   t2v = vconst(kc.tag2);
+    const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), onev = vconst(kc.one),
+                   dtv = vconst(kc.next4 + kc.tag2);               // 4|g| + 2: H'' tagged 3 -> D'' tagged 1
     // zero level of the row a lane did "before step 1": region 1 is at row t - gl, region 2 at row t - gl - LAG
     uint32_t Z1 = pk2(lin_base(g) + gl * g), Z2 = pk2(lin_base(g) + (gl + LAG) * g);
-    uint32_t G[CT], A[CT];                  // H and max(M, I) of the previous row (drifted)
-    uint32_t accO[QD * 4], accF[QD * 4];
+    uint32_t G[CT];                         // H of the previous row (drifted)
+    uint32_t acc[2 * NW];                   // op codes of the last (up to) eight steps, one column each
 #pragma unroll
-    for (int c = 0; c < CT; c++) { G[c] = c < C1 ? Z1 : Z2; A[c] = G[c]; }       // row 0: M = 0, I = -INF
+    for (int c = 0; c < CT; c++) G[c] = c < C1 ? Z1 : Z2;                          // row 0: H = 0
 #pragma unroll
-    for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
-    // last slot of each region as the neighbour lane will see it: B = max(M, D) and H.  On the j = 0 border both
-    // are the zero level (M = H = 0, D = -INF)
-    uint32_t B1 = Z1, H1 = Z1, B2 = Z2, H2 = Z2;
+    for (int c = 0; c < 2 * NW; c++) acc[c] = 0;
+    // last slot of each region as the neighbour lane will see it; on the j = 0 border it is the zero level
+    uint32_t H1 = Z1, H2 = Z2;
     uint32_t Hdiag1 = Z1, Hdiag2 = Z2;
 
     auto lut = [&](uint32_t amount) { return kc.dsub >> (amount & 31u); };
@@ -107,132 +131,99 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     }
 
-    // a plain slot, both phases of region 1 and the score-only phase of region 2
-    auto first = [&](uint32_t &Hd, uint32_t (&M)[CT], int c, uint32_t la, uint32_t lb, uint32_t Z) {
-        const uint32_t Mx = Hd + __builtin_amdgcn_perm(lb, la, qb[c]);               // align.cpp:134-144 (no carry)
+    // what a cell takes from the previous row: max(M, zero level, H_up), align.cpp:134-147 and the insertion of
+    // :149-154 as H_up (drifted: no addition; no carry in the plain add, all values positive)
+    auto upper = [&](uint32_t &Hd, int c, uint32_t la, uint32_t lb, uint32_t Z) {
+        const uint32_t Mx = Hd + __builtin_amdgcn_perm(lb, la, qb[c]);
         Hd = G[c];
-        M[c] = pk_max(Mx, Z);                                                        // :145-147
-    };
-    auto second = [&](uint32_t &Bl, const uint32_t (&M)[CT], int c) {
-        const uint32_t D = Bl - gv;                                                  // :151-156 (no borrow)
-        A[c] = pk_max(M[c], A[c]);                          // A[c] was this row's I (:149-154); now max(M, I)
-        Bl = pk_max(M[c], D);
-        G[c] = pk_max(A[c], D);                                                      // :158-160
+        return pk_max(pk_max(Mx, Z), G[c]);
     };
 
     auto step = [&](const int t) {
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
         Z1 += gv; Z2 += gv;
         // lane 0 of region 1 sits on the j = 0 border: the zero level
-        const uint32_t Bl1 = (uint32_t)dpp_row_shr1((int)B1, (int)Z1);
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
         // lane 0 of region 2 continues lane 15's region 1 (one step ago = same row, same zero level)
-        const uint32_t Bl2 = (uint32_t)dpp_row_shr1((int)B2, dpp_row_ror1((int)B1));
         const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)H1));
         uint32_t Hd = Hdiag1;
         Hdiag1 = Hl1;
-        uint32_t M[CT];
+        uint32_t U[CT];
 #pragma unroll
         for (int c = 0; c < CT; c++) {
             if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            first(Hd, M, c, c < C1 ? rb1 : rb2, c < C1 ? rb1b : rb2b, c < C1 ? Z1 : Z2);
+            U[c] = upper(Hd, c, c < C1 ? rb1 : rb2, c < C1 ? rb1b : rb2b, c < C1 ? Z1 : Z2);
         }
-        uint32_t Bl = Bl1;
+        uint32_t Hl = Hl1;
 #pragma unroll
         for (int c = 0; c < CT; c++) {
-            if (c == C1) { B1 = Bl; H1 = G[C1 - 1]; Bl = Bl2; }
-            second(Bl, M, c);
+            if (c == C1) { H1 = Hl; Hl = Hl2; }
+            G[c] = pk_max(U[c], Hl - gv);                                        // :151-160 (no borrow)
+            Hl = G[c];
         }
-        B2 = Bl; H2 = G[CT - 1];
+        H2 = Hl;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     };
 
-    // ---- pointer phase: region 2 on tagged scores.  Registers: G = 4H+3, A = 4 max(M, I) + {3: M, 2: I}; the
-    //      lane-boundary B2 = 4 max(M, D) + {3: M, 1: D}
+    // ---- pointer phase: region 2 on tagged scores; G = 4H + 3 there
     uint32_t Z24 = 0;
     auto step_tagged = [&](const int t) {
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
         Z1 += gv; Z24 += g4v;
-        const uint32_t Bl1 = (uint32_t)dpp_row_shr1((int)B1, (int)Z1);
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
-        // lane 15's region-1 column enters region 2 scaled; which of M and D its B came from is not known, and
-        // not needed: the tag only feeds the flag of region 2's first column, eight columns left of the window
-        const uint32_t Bl2 = (uint32_t)dpp_row_shr1((int)B2, dpp_row_ror1((int)pk_mad4(B1, kc.c3)));
+        // lane 15's region-1 column enters region 2 scaled and tagged 3
         const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4(H1, kc.c3)));
         uint32_t Hd = Hdiag1;
         Hdiag1 = Hl1;
-        uint32_t M[CT];
+        uint32_t U[CT];
 #pragma unroll
-        for (int c = 0; c < CT; c++) {
-            if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            first(Hd, M, c, c < C1 ? rb1 : rb2, c < C1 ? rb1b : rb2b, c < C1 ? Z1 : Z24);      // region 2: 4M + 3
+        for (int c = 0; c < C1; c++) U[c] = upper(Hd, c, rb1, rb1b, Z1);
+        Hd = Hdiag2; Hdiag2 = Hl2;
+#pragma unroll
+        for (int c = C1; c < CT; c++) {
+            const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb2b, rb2, qb[c]);      // 4M + 3
+            Hd = G[c];
+            U[c] = pk_max(pk_max(Mx, Z24), G[c] - onev);                         // H_up tagged 2
         }
-        uint32_t Bl = Bl1;
+        uint32_t Hl = Hl1;
 #pragma unroll
-        for (int c = 0; c < CT; c++) {
-            if (c == C1) { B1 = Bl; H1 = G[C1 - 1]; Bl = Bl2; }
-            if (c < C1) { second(Bl, M, c); continue; }
-            const uint32_t Dp = Bl - g4v;                    // low bits 3: del_open >= del_extend (:171), 1: not
-            const uint32_t Dt = andn_or(Dp, c3v, t1v);
-            const uint32_t It = andn_or(A[c], c3v, t2v);     // A[c]: low bits 3: ins_open >= ins_extend (:170), 2: not
-            accF[c - C1] = pk_shl_add4(accF[c - C1], (A[c] ^ Dp) & c3v);
-            A[c] = pk_max(M[c], It);
-            Bl = pk_max(M[c], Dt);
-            const uint32_t Hp = pk_max(A[c], Dt);                                        // :158-168
-            accO[c - C1] = pk_shl_add4(accO[c - C1], Hp & c3v);
+        for (int c = 0; c < C1; c++) { G[c] = pk_max(U[c], Hl - gv); Hl = G[c]; }
+        H1 = Hl; Hl = Hl2;
+#pragma unroll
+        for (int c = C1; c < CT; c++) {
+            const uint32_t Hp = pk_max(U[c], Hl - dtv);                          // the low bits: the op (:162-164)
+            acc[c - C1] = pk_shl_add4(acc[c - C1], Hp & c3v);
             G[c] = Hp | c3v;
+            Hl = G[c];
         }
-        B2 = Bl; H2 = G[CT - 1];
+        H2 = Hl;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8);
     };
     auto enter_tagged = [&]() {
 #pragma unroll
-        for (int c = C1; c < CT; c++) {
-            G[c] = pk_mad4(G[c], kc.c3);
-            A[c] = pk_mad4(A[c], kc.c3);        // which of M and I it was is only asked for rows above the window
-        }
-        B2 = pk_mad4(B2, kc.c3);
+        for (int c = C1; c < CT; c++) G[c] = pk_mad4(G[c], kc.c3);
         H2 = pk_mad4(H2, kc.c3);
         Hdiag2 = pk_mad4(Hdiag2, kc.c3);
         Z24 = pk_mad4(Z2, kc.c3);
         rb2 = rb2 << 2; rb2b = rb2b << 2;               // the row already fetched: bonus times four
     };
 
-    auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
-    auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
-
     int t = 1;
     for (; t < tB && t <= T_end; t++) step(t);
     const bool tagged = t <= T_end;
     if (tagged) enter_tagged();
-    // flush block layout: WsBlock (gact_device.hpp), compact when the last column quad holds one column (C2 = 13)
-    constexpr bool COMPACT = (C2 % 4) == 1;
-    constexpr int QF = COMPACT ? QD - 1 : QD;                  // full quads
-    constexpr int kBlockU4 = WsBlock<QD, kGroup, COMPACT>::kUint4;
     uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
     uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
-    auto flush = [&](auto fix) {
-#pragma unroll
-        for (int q = 0; q < QF; q++) {
-            qA[q * kGroup] = make_uint4(fix(wordA(accO[4 * q], accF[4 * q])), fix(wordA(accO[4 * q + 1], accF[4 * q + 1])),
-                                        fix(wordA(accO[4 * q + 2], accF[4 * q + 2])), fix(wordA(accO[4 * q + 3], accF[4 * q + 3])));
-            qB[q * kGroup] = make_uint4(fix(wordB(accO[4 * q], accF[4 * q])), fix(wordB(accO[4 * q + 1], accF[4 * q + 1])),
-                                        fix(wordB(accO[4 * q + 2], accF[4 * q + 2])), fix(wordB(accO[4 * q + 3], accF[4 * q + 3])));
-        }
-        if (COMPACT) {          // the last column: one dword per lane behind the full quads
-            reinterpret_cast<uint32_t *>(qA - gl + QF * kGroup)[gl] = fix(wordA(accO[4 * QF], accF[4 * QF]));
-            reinterpret_cast<uint32_t *>(qB - gl + QF * kGroup)[gl] = fix(wordB(accO[4 * QF], accF[4 * QF]));
-        }
-    };
+    auto flush = [&](auto fix) { lin_flush<NW, kGroup>(acc, qA, qB, fix); };
     // whole blocks of eight steps, each followed by its flush (an `if ((k & 7) == 7)` inside one loop is
-    // if-converted by the compiler: the 26 re-pairing v_perm of the flush would then run at every step)
+    // if-converted by the compiler: the re-pairing v_perm of the flush would then run at every step)
     int k = 0;
     while (t + 7 <= T_end) {
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
         flush([](uint32_t w) { return w; });
-        qA += kBlockU4;
-        qB += kBlockU4;
+        qA += QD * kGroup;
+        qB += QD * kGroup;
     }
     for (; t <= T_end; t++, k++) step_tagged(t);
     if (k & 7) {
@@ -259,19 +250,19 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
                                                 uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
                                                 const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb)
 {
-    constexpr int QD = (C + 3) / 4;
+    constexpr int NW = LinWords<C>::kWords, QD = LinWords<C>::kUint4;
     static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
-    const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), t1v = vconst(kc.tag1),
-                   t2v = vconst(kc.tag2);
+    const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), onev = vconst(kc.one),
+                   dtv = vconst(kc.next4 + kc.tag2);
     uint32_t Z = pk2(lin_base(g) + gl * g);      // zero level of the row this lane did "before step 1"
-    uint32_t G[C], A[C];                         // H and max(M, I) of the previous row (see dp_pass_lin_split)
-    uint32_t accO[QD * 4], accF[QD * 4];
+    uint32_t G[C];                               // H of the previous row (see dp_pass_lin_split)
+    uint32_t acc[2 * NW];
 #pragma unroll
-    for (int c = 0; c < C; c++) { G[c] = Z; A[c] = Z; }
+    for (int c = 0; c < C; c++) G[c] = Z;
 #pragma unroll
-    for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
-    uint32_t B_last = Z, G_last = Z, Hdiag = Z;
+    for (int c = 0; c < 2 * NW; c++) acc[c] = 0;
+    uint32_t G_last = Z, Hdiag = Z;
 
     // arg-max state (see dp_pass_p16)
     uint32_t bk[AMAX ? C : 1];
@@ -299,26 +290,20 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     auto step = [&](const int t) {
         const uint32_t w_next = ref16[t + 1];
         Z += gv;
-        const uint32_t Bl0 = shr1(B_last, Z);            // j = 0 border: the zero level
-        const uint32_t Hl = shr1(G_last, Z);
+        const uint32_t Hl0 = shr1(G_last, Z);            // j = 0 border: the zero level
         uint32_t Hd = Hdiag;
-        Hdiag = Hl;
-        uint32_t M[C];
+        Hdiag = Hl0;
+        uint32_t U[C];
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
             Hd = G[c];
-            M[c] = pk_max(Mx, Z);
+            U[c] = pk_max(pk_max(Mx, Z), G[c]);
         }
-        uint32_t Bl = Bl0;
+        uint32_t Hl = Hl0;
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            const uint32_t D = Bl - gv;
-            A[c] = pk_max(M[c], A[c]);
-            Bl = pk_max(M[c], D);
-            G[c] = pk_max(A[c], D);
-        }
-        B_last = Bl; G_last = G[C - 1];
+        for (int c = 0; c < C; c++) { G[c] = pk_max(U[c], Hl - gv); Hl = G[c]; }
+        G_last = Hl;
         lutA = lut(w_next & 0xffu); lutB = lut(w_next >> 8);
     };
 
@@ -334,50 +319,37 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
             const uint32_t kb = row0 < (uint32_t)rows[1] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
             key_c = pk_sub(ka | (kb << 16), Z8);
         }
-        const uint32_t Bl0 = shr1(B_last, Z4);
-        const uint32_t Hl = shr1(G_last, Z4);
+        const uint32_t Hl0 = shr1(G_last, Z4);
         uint32_t Hd = Hdiag;
-        Hdiag = Hl;
-        uint32_t M[C];
+        Hdiag = Hl0;
+        uint32_t U[C];
 #pragma unroll
         for (int c = 0; c < C; c++) {
             const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
             Hd = G[c];
-            M[c] = pk_max(Mx, Z4);
+            U[c] = pk_max(pk_max(Mx, Z4), G[c] - onev);
         }
-        uint32_t Bl = Bl0;
+        uint32_t Hl = Hl0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t Dp = Bl - g4v;
-            const uint32_t Dt = andn_or(Dp, c3v, t1v);
-            const uint32_t It = andn_or(A[c], c3v, t2v);
-            accF[c] = pk_shl_add4(accF[c], (A[c] ^ Dp) & c3v);
-            A[c] = pk_max(M[c], It);
-            Bl = pk_max(M[c], Dt);
-            const uint32_t Hp = pk_max(A[c], Dt);
-            accO[c] = pk_shl_add4(accO[c], Hp & c3v);
+            const uint32_t Hp = pk_max(U[c], Hl - dtv);
+            acc[c] = pk_shl_add4(acc[c], Hp & c3v);
             G[c] = Hp | c3v;
+            Hl = G[c];
             if (AMAX) bk[c] = pk_max(bk[c], pk_mad_vvv(G[c], kc.tag2, key_c));      // 2 G'' + (step & 7) - 2 Z''
         }
-        B_last = Bl; G_last = G[C - 1];
+        G_last = Hl;
         lutA = lut4(w_next & 0xffu); lutB = lut4(w_next >> 8);
     };
     auto enter_tagged = [&]() {
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            G[c] = pk_mad4(G[c], kc.c3);
-            A[c] = pk_mad4(A[c], kc.c3);
-        }
-        B_last = pk_mad4(B_last, kc.c3);
+        for (int c = 0; c < C; c++) G[c] = pk_mad4(G[c], kc.c3);
         G_last = pk_mad4(G_last, kc.c3);
         Hdiag = pk_mad4(Hdiag, kc.c3);
         Z4 = pk_mad4(Z, kc.c3);
         Z8 = Z4 + Z4;
         lutA <<= 2; lutB <<= 2;
     };
-
-    auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
-    auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
 
     // fold the block keys of stored steps kblk..kblk+7 into lane_best (as dp_pass_p16)
     auto fold = [&](const int kblk) {
@@ -411,13 +383,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     while (t + 7 <= T_end) {                     // whole blocks of eight steps + flush (see dp_pass_lin_split)
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
-#pragma unroll
-        for (int q = 0; q < QD; q++) {
-            qA[q * LANES] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
-                                       wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
-            qB[q * LANES] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
-                                       wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
-        }
+        lin_flush<NW, LANES>(acc, qA, qB, [](uint32_t w) { return w; });
         qA += QD * LANES;
         qB += QD * LANES;
         if (AMAX) fold(k - 8);
@@ -449,14 +415,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     }
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
-        auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
-#pragma unroll
-        for (int q = 0; q < QD; q++) {
-            qA[q * LANES] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
-                                       just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
-            qB[q * LANES] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
-                                       just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
-        }
+        lin_flush<NW, LANES>(acc, qA, qB, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); });
     }
     if (AMAX) return 0;
     // H[R][Q]: slot cq of the lane that owns column Q, at the row of the last step; drift taken off
@@ -469,7 +428,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 
 // The wide main launch of linear scorings: UniformLayout<10, 32>'s column map, the pass above, FMT 3 words
 struct WideLayoutLin : UniformLayout<10, 32, true> {
-    static constexpr int kWalkFmt = 3;
+    static constexpr int kWalkFmt = 3, kWalkQuads = LinWords<10>::kUint4;
     static constexpr bool kEndAligned = true;
     template <bool RAW>
     __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[10], int T_end,
@@ -488,9 +447,8 @@ struct WideLayoutLin : UniformLayout<10, 32, true> {
 #endif
 template <int C1, int C2> struct SplitLayoutLin : SplitLayout<C1, C2, true> {
     static constexpr int kBlocksPerCu = GACT_LIN_BLOCKS_PER_CU;
-    static constexpr int kWalkFmt = 3;
+    static constexpr int kWalkFmt = 3, kWalkQuads = LinWords<C2>::kUint4;
     static constexpr bool kEndAligned = true;       // every tile's last row on the wave's last step
-    static constexpr bool kWalkCompact = (C2 % 4) == 1;
     template <bool RAW>
     __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],
                                     int T_end, int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &pt)

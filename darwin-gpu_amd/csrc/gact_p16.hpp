@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
                 const int i0 = h ? pb.bi[1] : pb.bi[0], j0 = h ? pb.bj[1] : pb.bj[0];
                 const int l0 = (j0 - 1) / C;
                 // (FMT 3 walkers start from the score of their cell: the arg-max)
-                walk_chain<C, LIN ? 3 : 1, C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
+                walk_chain<C, LIN ? 3 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
                                                   i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
                                                   s.phase, kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0]);
             }

@@ -131,12 +131,30 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     }
 
-    // what a cell takes from the previous row: max(M, zero level, H_up), align.cpp:134-147 and the insertion of
-    // :149-154 as H_up (drifted: no addition; no carry in the plain add, all values positive)
-    auto upper = [&](uint32_t &Hd, int c, uint32_t la, uint32_t lb, uint32_t Z) {
-        const uint32_t Mx = Hd + __builtin_amdgcn_perm(lb, la, qb[c]);
-        Hd = G[c];
-        return pk_max(pk_max(Mx, Z), G[c]);
+    // Instruction order.  With three waves on a SIMD a v_add / v_sub / v_and / v_or issues in 1.9 cycles when it does
+    // not wait for the instruction in front of it, in 3.0 when it does (issue_rate_probe.json, dependent streams).
+    // So the step is written in stages -- one kind of instruction for all column slots, then the next kind -- and the
+    // two regions' column chains (H_left -> D -> H, two dependent instructions per slot) run side by side; the
+    // scheduling barriers keep the compiler from folding the stages back into per-slot sequences.
+#define GACT_SB() __builtin_amdgcn_sched_barrier(0)
+    auto upper_all = [&](uint32_t (&U)[CT], const bool tag2, const uint32_t Zr2) {
+        uint32_t P[CT];
+#pragma unroll
+        for (int c = 0; c < CT; c++) P[c] = __builtin_amdgcn_perm(c < C1 ? rb1b : rb2b, c < C1 ? rb1 : rb2, qb[c]);
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < CT; c++) U[c] = (c == 0 ? Hdiag1 : c == C1 ? Hdiag2 : G[c - 1]) + P[c];   // align.cpp:134-144
+        if (tag2) {
+#pragma unroll
+            for (int c = C1; c < CT; c++) P[c] = G[c] - onev;                    // H_up tagged 2
+        }
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], c < C1 ? Z1 : Zr2);     // :145-147
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], (tag2 && c >= C1) ? P[c] : G[c]);    // the insertion, :149-154
+        GACT_SB();
     };
 
     auto step = [&](const int t) {
@@ -146,22 +164,22 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
         // lane 0 of region 2 continues lane 15's region 1 (one step ago = same row, same zero level)
         const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)H1));
-        uint32_t Hd = Hdiag1;
-        Hdiag1 = Hl1;
         uint32_t U[CT];
+        upper_all(U, false, Z2);
+        Hdiag1 = Hl1; Hdiag2 = Hl2;
+        uint32_t Ha = Hl1, Hb = Hl2;
+        static_assert(C2 >= C1, "region 2 is the longer chain");
 #pragma unroll
-        for (int c = 0; c < CT; c++) {
-            if (c == C1) { Hd = Hdiag2; Hdiag2 = Hl2; }
-            U[c] = upper(Hd, c, c < C1 ? rb1 : rb2, c < C1 ? rb1b : rb2b, c < C1 ? Z1 : Z2);
+        for (int c = 0; c < C1; c++) {                                           // :151-160 (no borrow)
+            const uint32_t Da = Ha - gv, Db = Hb - gv;
+            GACT_SB();
+            G[c] = pk_max(U[c], Da); G[C1 + c] = pk_max(U[C1 + c], Db);
+            GACT_SB();
+            Ha = G[c]; Hb = G[C1 + c];
         }
-        uint32_t Hl = Hl1;
 #pragma unroll
-        for (int c = 0; c < CT; c++) {
-            if (c == C1) { H1 = Hl; Hl = Hl2; }
-            G[c] = pk_max(U[c], Hl - gv);                                        // :151-160 (no borrow)
-            Hl = G[c];
-        }
-        H2 = Hl;
+        for (int c = 2 * C1; c < CT; c++) { G[c] = pk_max(U[c], Hb - gv); Hb = G[c]; }
+        H1 = Ha; H2 = Hb;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     };
 
@@ -173,32 +191,32 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
         // lane 15's region-1 column enters region 2 scaled and tagged 3
         const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4(H1, kc.c3)));
-        uint32_t Hd = Hdiag1;
-        Hdiag1 = Hl1;
         uint32_t U[CT];
+        upper_all(U, true, Z24);
+        Hdiag1 = Hl1; Hdiag2 = Hl2;
+        uint32_t Ha = Hl1, Hb = Hl2;
+        uint32_t tprev = 0;
 #pragma unroll
-        for (int c = 0; c < C1; c++) U[c] = upper(Hd, c, rb1, rb1b, Z1);
-        Hd = Hdiag2; Hdiag2 = Hl2;
-#pragma unroll
-        for (int c = C1; c < CT; c++) {
-            const uint32_t Mx = Hd + __builtin_amdgcn_perm(rb2b, rb2, qb[c]);      // 4M + 3
-            Hd = G[c];
-            U[c] = pk_max(pk_max(Mx, Z24), G[c] - onev);                         // H_up tagged 2
+        for (int c = 0; c < C2; c++) {
+            const bool both = c < C1;
+            uint32_t Da = 0;
+            const uint32_t Db = Hb - dtv;                                        // H'' tagged 3 -> D'' tagged 1
+            if (both) Da = Ha - gv;
+            GACT_SB();
+            const uint32_t Hp = pk_max(U[C1 + c], Db);                           // the low bits: the op (:162-164)
+            if (both) { G[c] = pk_max(U[c], Da); Ha = G[c]; }
+            if (c > 0) acc[c - 1] = pk_shl_add4(acc[c - 1], tprev);
+            GACT_SB();
+            G[C1 + c] = Hp | c3v;
+            tprev = Hp & c3v;
+            GACT_SB();
+            Hb = G[C1 + c];
         }
-        uint32_t Hl = Hl1;
-#pragma unroll
-        for (int c = 0; c < C1; c++) { G[c] = pk_max(U[c], Hl - gv); Hl = G[c]; }
-        H1 = Hl; Hl = Hl2;
-#pragma unroll
-        for (int c = C1; c < CT; c++) {
-            const uint32_t Hp = pk_max(U[c], Hl - dtv);                          // the low bits: the op (:162-164)
-            acc[c - C1] = pk_shl_add4(acc[c - C1], Hp & c3v);
-            G[c] = Hp | c3v;
-            Hl = G[c];
-        }
-        H2 = Hl;
+        acc[C2 - 1] = pk_shl_add4(acc[C2 - 1], tprev);
+        H1 = Ha; H2 = Hb;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8);
     };
+#undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
         for (int c = C1; c < CT; c++) G[c] = pk_mad4(G[c], kc.c3);

@@ -137,6 +137,10 @@ __device__ __forceinline__ bool chain_first_tile(ChainState &s, const KParams &k
     return false;
 }
 
+#ifdef GACT_STAMPS
+__device__ unsigned long long g_refill_clocks;      // diagnostic build: shader clocks spent in the walker's region refills
+#endif
+
 // running rescoring state of one candidate while its states stream by
 struct ScoreWalk {
     int score, pend_gap, open_flag, have_left, left_first_gap;
@@ -159,6 +163,99 @@ struct ScoreWalk {
         }
     }
 };
+
+// The walker of the linear-gap pass (FMT 3 words, gact_lin.hpp: gap_open == gap_extend == mismatch =: g): the pointer is the op code alone,
+// op = which of M, H_up + g, H_left + g made H (ties M, then I, then D -- the order of align.cpp:162-164).
+//   * No flags.  align.cpp:218-229 leaves INSERT at (i, j) for MATCH iff M[i-1][j] >= I[i-1][j].  The walk is in
+//     INSERT at (i, j) only when I[i][j] > M[i][j]; were D the strict maximum at (i-1, j), then
+//     I[i][j] < D[i-1][j] + g <= H[i-1][j-1] + 2g <= H[i-1][j-1] + mismatch <= M[i][j].  So the op of (i-1, j) is
+//     MATCH or INSERT there, and says exactly what the flag says; DELETE likewise with (i, j-1).  The next state is
+//     the op of the cell the walk enters, whatever the move.  (tools/lin_walk_model.py checks the rule against
+//     the oracle on random tiles; tests/test_gpu_chain.py the kernels.)
+//   * No ZERO: H == 0 is the one case the tagged max cannot tell from M == H.  The walker carries the score of the
+//     cell it stands on, v (H of the start cell comes from the pass: v0), and every move takes the move's own
+//     score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE step g; after a diagonal
+//     move v is H of the new cell, and ZERO means v == 0 (align.cpp:166-168: M <= 0, I <= 0, D <= 0, i.e. H == 0).
+// Position arithmetic, region cache and arguments as in walk_chain below.
+template <int CW, int QN, int LANES>
+__device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
+                                               int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
+                                               const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
+                                               int &nst, int v0)
+{
+    constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
+    constexpr uint32_t kM = 3u, kI = 2u, kD = 1u;               // align.h:23 numbering, as the pass tags them
+    const int p0 = l0 * CW + c0, kA = k0 - l0;
+    const int nlim_i = -imin(early, R), nlim_j = -imin(early, Q);
+    typedef __attribute__((address_space(3))) const uint8_t LdsByte;
+    typedef __attribute__((address_space(3))) const uint32_t LdsWord;
+    LdsByte *ra = (LdsByte *)(rrow + (R - 1) * rstride);
+    LdsByte *qa = (LdsByte *)(qrow + (Q - 1));
+    LdsByte *cache = (LdsByte *)scratch;
+    int nis = 0, njs = 0;                                       // minus the ref / query steps taken
+    uint32_t cur = 0;
+    TbRegion<CW> rg;
+    int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
+#ifdef GACT_STAMPS
+    unsigned long long rf_clk = 0;
+#endif
+    // region cache: dword (c >> 1) + 8 * (k >> 3) of a lane's two cached blocks x two cached octets
+    auto refill = [&](int l, int c, int k) {
+#ifdef GACT_STAMPS
+        struct Acc { unsigned long long &sum, t0; __device__ ~Acc() { sum += __builtin_amdgcn_s_memtime() - t0; } } acc_{rf_clk, __builtin_amdgcn_s_memtime()};
+#endif
+        tb_refill_oct<CW, QN, LANES>(ws, scratch, l, c, k, rg);
+        off0 = 4 * (-8 * rg.fbase[0] - 4 * rg.qbase0);
+        off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
+    };
+    auto fetch = [&](int l, int c, int k) {
+        const uint32_t at = (uint32_t)((2 * c & ~3) + (int)(((uint32_t)k >> 3) << 5) + (l == rg.l0 ? off0 : off1));
+        const uint32_t w = *(LdsWord *)(cache + at);
+        return (w >> (((~(uint32_t)k & 7u) * 2u) | (((uint32_t)c & 1u) << 4))) & 3u;
+    };
+    // the three column scores in VGPRs (a select between kp's fields themselves is turned into an indexed load
+    // from the kernel argument segment, one memory round trip per step)
+    int v = v0, v_gap, v_mism, v_match;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v_gap) : "s"(__builtin_amdgcn_readfirstlane(kp.ext)));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v_mism) : "s"(__builtin_amdgcn_readfirstlane(kp.mismatch)));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v_match) : "s"(__builtin_amdgcn_readfirstlane(kp.match)));
+    uint32_t rbase = 0, qbase = 0;                              // bases of the current cell
+    if (R >= 1 && Q >= 1 && early > 0) {
+        refill(l0, c0, k0);
+        cur = v == 0 ? 0u : fetch(l0, c0, k0);
+        rbase = ra[0]; qbase = qa[0];
+    }
+    for (int it = 0; cur != 0; it++) {
+        // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209): its score comes off v.  With
+        //      gap_open == gap_extend that running sum is also all the rescoring of gact.cpp:197-210 needs
+        const bool diag = cur == kM;
+        const int sub = rbase == qbase ? v_match : v_mism;
+        v -= diag ? sub : v_gap;
+        // ---- move (align.cpp:210-229)
+        nis -= cur != kD;
+        njs -= cur != kI;
+        // (a walker that is about to stop may have left the tile: keep its addresses inside the stored window)
+        const int p = imax(p0 + njs, 0);
+        const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
+        const int c = p + __mul24(l, -CW);
+        const int k = imax(kA + l + nis, 0);
+        if ((it & 7) == 7) refill(l, c, k);
+        // the op and the bases of the cell just entered: three LDS reads in flight together.  The op is the next
+        // state whatever the move was (see above); ZERO is only asked for after a diagonal move (align.cpp:211-212
+        // against :219, :225)
+        const uint32_t code = fetch(l, c, k);
+        rbase = ra[nis * rstride]; qbase = qa[njs];
+        const uint32_t nxt = (diag && v == 0) ? 0u : code;
+        cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
+    }
+#ifdef GACT_STAMPS
+    if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_refill_clocks, rf_clk);
+#endif
+    ref_steps = -nis; query_steps = -njs;
+    nst = -nis - njs;                                            // only "were there any columns" is asked (chain_advance)
+    wk.score += v0 - v;                                          // what the columns of this tile scored
+    // (open == extend: the gap bookkeeping of wk decides nothing)
+}
 
 // The chain kernels' walker: traceback (align.cpp:185-230) fused with the rescoring
 // of gact.cpp:197-210, written for few instructions per step -- every step of a
@@ -183,24 +280,17 @@ struct ScoreWalk {
 // byte stride.  (l0, c0, k0) = lane, column-in-lane and stored step of the start cell
 // (R, Q) in the pass's layout; CW columns per lane, QN column quads stored per lane.
 //
-// FMT 3 (linear-gap pass, gact_lin.hpp: gap_open == gap_extend == mismatch =: g): the pointer is the op code alone,
-// op = which of M, H_up + g, H_left + g made H (ties M, then I, then D -- the order of align.cpp:162-164).
-//   * No flags.  align.cpp:218-229 leaves INSERT at (i, j) for MATCH iff M[i-1][j] >= I[i-1][j].  The walk is in
-//     INSERT at (i, j) only when I[i][j] > M[i][j]; were D the strict maximum at (i-1, j), then
-//     I[i][j] < D[i-1][j] + g <= H[i-1][j-1] + 2g <= H[i-1][j-1] + mismatch <= M[i][j].  So the op of (i-1, j) is
-//     MATCH or INSERT there, and says exactly what the flag says; DELETE likewise with (i, j-1).  The next state is
-//     the op of the cell the walk enters, whatever the move.  (tools/lin_walk_model.py checks the rule against
-//     the oracle on random tiles; tests/test_gpu_chain.py the kernels.)
-//   * No ZERO: H == 0 is the one case the tagged max cannot tell from M == H.  The walker carries the score of the
-//     cell it stands on, v (H of the start cell comes from the pass: v0), and every move takes the move's own
-//     score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE step g; after a diagonal
-//     move v is H of the new cell, and ZERO means v == 0 (align.cpp:166-168: M <= 0, I <= 0, D <= 0, i.e. H == 0).
 template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup, bool COMPACT = false>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
                                            int &query_steps, int &nst, int v0 = 0)
 {
+    if constexpr (FMT == 3) {
+        walk_chain_lin<CW, QN, LANES>(ws, scratch, R, Q, l0, c0, k0, early, rrow, rstride, qrow, kp, wk, ref_steps,
+                                      query_steps, nst, v0);
+        return;
+    }
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     const bool left = phase == 0;
     const int p0 = l0 * CW + c0, kA = k0 - l0;
@@ -214,12 +304,6 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
-        if (FMT == 3) {         // dword (c >> 1) + 8 * (k >> 3) of a lane's two cached blocks x two cached octets
-            tb_refill_oct<CW, QN, LANES>(ws, scratch, l, c, k, rg);
-            off0 = 4 * (-8 * rg.fbase[0] - 4 * rg.qbase0);
-            off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
-            return;
-        }
         tb_refill_at<CW, QN, LANES, COMPACT>(ws, scratch, l, c, k, rg);
         off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
@@ -229,12 +313,6 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     typedef __attribute__((address_space(3))) const uint32_t LdsWord;
     LdsByte *cache = (LdsByte *)scratch;
     auto fetch = [&](int l, int c, int k, uint32_t &code, uint32_t &flags) {
-        if (FMT == 3) {
-            const uint32_t at = (uint32_t)((2 * c & ~3) + (int)(((uint32_t)k >> 3) << 5) + (l == rg.l0 ? off0 : off1));
-            const uint32_t w = *(LdsWord *)(cache + at);
-            code = (w >> (((~(uint32_t)k & 7u) * 2u) | (((uint32_t)c & 1u) << 4))) & 3u;
-            return;
-        }
         const uint32_t at = (uint32_t)(4 * c + (int)__umul24((uint32_t)k >> 3, 48u) + (l == rg.l0 ? off0 : off1));
         const uint32_t w = *(LdsWord *)(cache + at);
         if (FMT == 1) {
@@ -253,20 +331,14 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         }
     };
 
-    int v = v0;                                                 // FMT 3: H of the current cell
-    int v_gap, v_mism, v_match;                                 // the three column scores, in VGPRs (see the loop)
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v_gap) : "s"(__builtin_amdgcn_readfirstlane(kp.ext)));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v_mism) : "s"(__builtin_amdgcn_readfirstlane(kp.mismatch)));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v_match) : "s"(__builtin_amdgcn_readfirstlane(kp.match)));
     if (R >= 1 && Q >= 1 && early > 0) {
         refill(l0, c0, k0);
         fetch(l0, c0, k0, cur, fl);
-        if (FMT == 3 && v == 0) cur = 0;
     }
     // state numbering of the walk: FMT 0 / 1 words are turned into the packed kernel's op codes (1 MATCH 2 INSERT
     // 3 DELETE, flag set = the gap goes on); FMT 2 words carry align.h:23 numbering (3 MATCH 2 INSERT 1 DELETE) and
     // flags that say the opposite (set = the gap was opened here), and the walk uses them as they are
-    constexpr uint32_t kM = FMT >= 2 ? 3u : 1u, kI = 2u, kD = FMT >= 2 ? 1u : 3u;
+    constexpr uint32_t kM = FMT == 2 ? 3u : 1u, kI = 2u, kD = FMT == 2 ? 1u : 3u;
     if (left && !wk.have_left && cur != 0) { wk.have_left = 1; wk.left_first_gap = cur != kM; }
     // conditions live as lane masks on the scalar unit; a counter takes one as the carry of a single VALU op
     const uint64_t left_m = lanes(left);
@@ -275,20 +347,11 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209)
         const uint64_t g = lanes(cur != kM);
         const uint64_t eq = lanes(ra[nis * rstride] == qa[njs]);
-        if (FMT == 3) {
-            // the score of this column comes off v.  With gap_open == gap_extend that running sum is also all the
-            // rescoring of gact.cpp:197-210 needs: no event counters, no open / extend bookkeeping in this walk.
-            // (Scalars held in registers: a select between kp's fields themselves is turned into an indexed load
-            // from the kernel argument segment, one memory round trip per step.)
-            const int sub = select_lane_bit(eq, v_match, v_mism);
-            v -= select_lane_bit(g, v_gap, sub);
-        } else {
-            n_ext = add_lane_bit(n_ext, gprev & g);
-            n_open = add_lane_bit(n_open, (gprev ^ g) & ((left_m & gprev) | (~left_m & g)));
-            n_m = add_lane_bit(n_m, ~g);
-            n_eq = add_lane_bit(n_eq, ~g & eq);
-            gprev = (gprev & ~lanes(true)) | g;                   // walkers that have stopped keep their last column
-        }
+        n_ext = add_lane_bit(n_ext, gprev & g);
+        n_open = add_lane_bit(n_open, (gprev ^ g) & ((left_m & gprev) | (~left_m & g)));
+        n_m = add_lane_bit(n_m, ~g);
+        n_eq = add_lane_bit(n_eq, ~g & eq);
+        gprev = (gprev & ~lanes(true)) | g;                       // walkers that have stopped keep their last column
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
         nis = sub_lane_bit(nis, lanes(cur != kD));
         njs = sub_lane_bit(njs, lanes(cur != kI));
@@ -301,17 +364,10 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         if ((it & 7) == 7) refill(l, c, k);
         uint32_t code;
         fetch(l, c, k, code, fl);
-        // FMT 3: the op of the cell just entered is the next state whatever the move was (see above); ZERO is
-        // only asked for after a diagonal move (align.cpp:211-212 against :219, :225)
-        const uint32_t nxt = FMT == 3 ? ((cur == kM && v == 0) ? 0u : code) : (cur == kM ? code : forced);
+        const uint32_t nxt = cur == kM ? code : forced;
         cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
     }
     ref_steps = -nis; query_steps = -njs;
-    if (FMT == 3) {
-        nst = -nis - njs;                                        // only "were there any columns" is asked (chain_advance)
-        wk.score += v0 - v;                                      // what the columns of this tile scored
-        return;                                                  // open == extend: the gap bookkeeping of wk decides nothing
-    }
     nst = -nis - njs - n_m;
     wk.score += n_ext * kp.ext + n_open * kp.open + n_eq * kp.match + (n_m - n_eq) * kp.mismatch;
     const bool last_gap = (gprev >> (threadIdx.x & 63)) & 1;

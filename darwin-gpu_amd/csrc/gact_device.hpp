@@ -90,13 +90,6 @@ __device__ __forceinline__ int add_lane_bit(int x, uint64_t lane_mask)
     asm("s_nop 1\n\tv_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(r), "=s"(carry_out) : "v"(x), "s"(lane_mask));
     return r;
 }
-// bit(lane) ? a : b
-__device__ __forceinline__ int select_lane_bit(uint64_t lane_mask, int a, int b)
-{
-    int r;
-    asm("s_nop 1\n\tv_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(lane_mask));
-    return r;
-}
 __device__ __forceinline__ int sub_lane_bit(int x, uint64_t lane_mask)
 {
     int r;

@@ -985,6 +985,10 @@ int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_stamps2), z, sizeof z));
     if (y[3]) printf("  load_pair: fill %llu, loads %llu, lds-writes %llu clocks/iter\n", y[0] / y[3], y[1] / y[3], y[2] / y[3]);
     if (y[6]) printf("  load_pair_packed: fill + staging %llu, cutting %llu clocks/iter\n", y[4] / y[6], y[5] / y[6]);
+    unsigned long long rf = 0, zero = 0;
+    HIP_TRY(hipMemcpyFromSymbol(&rf, HIP_SYMBOL(gact::g_refill_clocks), sizeof rf));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_refill_clocks), &zero, sizeof zero));
+    if (y[6]) printf("  walker region refills: %llu clocks/iter\n", rf / y[6]);
     return 0;
 }
 #endif

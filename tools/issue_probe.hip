@@ -23,7 +23,7 @@
     {                                                                                                 \
         uint32_t a[N_ACC];                                                                            \
         _Pragma("unroll") for (int k = 0; k < N_ACC; k++) a[k] = seed * (k + 3) + threadIdx.x;        \
-        const uint32_t x = seed | 1, y = seed ^ 0x00030003u;                                          \
+        uint32_t x = seed | 1; const uint32_t y = seed ^ 0x00030003u;                                          \
         (void)x; (void)y;                                                                             \
         __syncthreads();                                                                              \
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                   \
@@ -69,6 +69,22 @@ PROBE(p_lin_slot,
                    "v_pk_max_i16 %0, %0, %2\n\tv_pk_add_i16 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %2" : "+v"(a[k]) : "v"(x), "v"(y));,
       asm volatile("v_perm_b32 %0, %1, %2, %0\n\tv_pk_add_i16 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1\n\t"
                    "v_pk_max_i16 %0, %0, %2\n\tv_pk_add_i16 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %2" : "+v"(a[0]) : "v"(x), "v"(y));)
+
+// mixed streams: does the order of fast-class (v_add_u32) and slow-class (v_pk_max_i16) instructions matter?
+//   alternating: add, max, add, max ... each on its own accumulator (independent) / each reading the one before
+//   (dependent: add -> max -> add ...);  blocks: eight adds, then eight maxes
+PROBE(p_alt_add_max,
+      asm volatile("v_add_u32 %0, %0, %2\n\tv_pk_max_i16 %1, %1, %2" : "+v"(a[k]), "+v"(a[(k + 8) % N_ACC]) : "v"(x));,
+      asm volatile("v_add_u32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[0]) : "v"(x));)
+PROBE(p_blk_add_max,
+      if (k < 8) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(x)); else asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[k]) : "v"(x));,
+      if (k < 8) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[0]) : "v"(x)); else asm volatile("v_pk_max_i16 %0, %0, %1" : "+v"(a[1]) : "v"(x));)
+// the chain of the linear-gap step: sub -> max -> sub -> max; one chain / two chains side by side
+PROBE(p_chain_sub_max,
+      asm volatile("v_sub_u32 %0, %1, %2\n\tv_sub_u32 %3, %4, %2\n\tv_pk_max_i16 %1, %0, %2\n\tv_pk_max_i16 %4, %3, %2"
+                   : "+v"(a[2]), "+v"(a[0]), "+v"(x) , "+v"(a[3]), "+v"(a[1]));,
+      asm volatile("v_sub_u32 %0, %1, %2\n\tv_pk_max_i16 %1, %0, %2\n\tv_sub_u32 %0, %1, %2\n\tv_pk_max_i16 %1, %0, %2"
+                   : "+v"(a[2]), "+v"(a[0]), "+v"(x));)
 
 struct Cell { double wave_cycles, simd_cycles; };
 
@@ -143,6 +159,9 @@ int main()
     ROW("v_add_u32 (SGPR operand)", p_add_sgpr, 1)
     ROW("v_fma_f32", p_fma_f32, 1)
     ROW("GACT linear-gap slot (perm, 2 add, 5 max)", p_lin_slot, 8)
+    ROW("v_add_u32, v_pk_max_i16 alternating", p_alt_add_max, 2)
+    ROW("8 x v_add_u32 then 8 x v_pk_max_i16", p_blk_add_max, 1)
+    ROW("sub -> max chains: independent = two side by side, dependent = one", p_chain_sub_max, 4)
     printf("\n ]}\n");
     return 0;
 }

@@ -305,22 +305,38 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         return (uint32_t)(LANES == 32 ? dpp_shr1_32((int)v, (int)old) : dpp_row_shr1((int)v, (int)old));
     };
 
+    // (stages of one instruction kind over all slots, as in dp_pass_lin_split)
+#define GACT_SB() __builtin_amdgcn_sched_barrier(0)
+    auto upper_all = [&](uint32_t (&U)[C], const bool tag2, const uint32_t Zr) {
+        uint32_t P[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) P[c] = __builtin_amdgcn_perm(lutB, lutA, qb[c]);
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C; c++) U[c] = (c == 0 ? Hdiag : G[c - 1]) + P[c];                 // align.cpp:134-144
+        if (tag2) {
+#pragma unroll
+            for (int c = 0; c < C; c++) P[c] = G[c] - onev;                                    // H_up tagged 2
+        }
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C; c++) U[c] = pk_max(U[c], Zr);                                   // :145-147
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C; c++) U[c] = pk_max(U[c], tag2 ? P[c] : G[c]);                   // the insertion, :149-154
+        GACT_SB();
+    };
+
     auto step = [&](const int t) {
         const uint32_t w_next = ref16[t + 1];
         Z += gv;
         const uint32_t Hl0 = shr1(G_last, Z);            // j = 0 border: the zero level
-        uint32_t Hd = Hdiag;
-        Hdiag = Hl0;
         uint32_t U[C];
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
-            Hd = G[c];
-            U[c] = pk_max(pk_max(Mx, Z), G[c]);
-        }
+        upper_all(U, false, Z);
+        Hdiag = Hl0;
         uint32_t Hl = Hl0;
 #pragma unroll
-        for (int c = 0; c < C; c++) { G[c] = pk_max(U[c], Hl - gv); Hl = G[c]; }
+        for (int c = 0; c < C; c++) { G[c] = pk_max(U[c], Hl - gv); Hl = G[c]; }               // :151-160
         G_last = Hl;
         lutA = lut(w_next & 0xffu); lutB = lut(w_next >> 8);
     };
@@ -338,27 +354,31 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
             key_c = pk_sub(ka | (kb << 16), Z8);
         }
         const uint32_t Hl0 = shr1(G_last, Z4);
-        uint32_t Hd = Hdiag;
-        Hdiag = Hl0;
         uint32_t U[C];
+        upper_all(U, true, Z4);
+        Hdiag = Hl0;
+        uint32_t Hl = Hl0, tprev = 0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t Mx = Hd + __builtin_amdgcn_perm(lutB, lutA, qb[c]);
-            Hd = G[c];
-            U[c] = pk_max(pk_max(Mx, Z4), G[c] - onev);
-        }
-        uint32_t Hl = Hl0;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const uint32_t Hp = pk_max(U[c], Hl - dtv);
-            acc[c] = pk_shl_add4(acc[c], Hp & c3v);
+            const uint32_t Db = Hl - dtv;                                                       // H'' tagged 3 -> D'' tagged 1
+            GACT_SB();
+            const uint32_t Hp = pk_max(U[c], Db);                                               // the low bits: the op (:162-164)
+            if (c > 0) {
+                acc[c - 1] = pk_shl_add4(acc[c - 1], tprev);
+                if (AMAX) bk[c - 1] = pk_max(bk[c - 1], pk_mad_vvv(G[c - 1], kc.tag2, key_c)); // 2 G'' + (step & 7) - 2 Z''
+            }
+            GACT_SB();
             G[c] = Hp | c3v;
+            tprev = Hp & c3v;
+            GACT_SB();
             Hl = G[c];
-            if (AMAX) bk[c] = pk_max(bk[c], pk_mad_vvv(G[c], kc.tag2, key_c));      // 2 G'' + (step & 7) - 2 Z''
         }
+        acc[C - 1] = pk_shl_add4(acc[C - 1], tprev);
+        if (AMAX) bk[C - 1] = pk_max(bk[C - 1], pk_mad_vvv(G[C - 1], kc.tag2, key_c));
         G_last = Hl;
         lutA = lut4(w_next & 0xffu); lutB = lut4(w_next >> 8);
     };
+#undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
         for (int c = 0; c < C; c++) G[c] = pk_mad4(G[c], kc.c3);

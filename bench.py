@@ -76,12 +76,13 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
 # wave64 VALU instruction; the kernels work on int16 pairs, two cells per slot.  Per cell PAIR the recurrence of
 # align.cpp:134-160 needs, in the cheapest formulation known for the scoring in use,
 #   affine gaps (any scoring):          11 ops for the scores, 11 more where traceback pointers are made
-#   linear gaps (open == extend == mismatch, the reference's params.cfg): 7 and 7 more (gact_lin.hpp)
+#   linear gaps (open == extend == mismatch, the reference's params.cfg): 6 and 4 more (gact_lin.hpp: H alone,
+#                                                                          op-only pointers)
 # and pointers are needed only inside the window a non-first tile's traceback can reach: early x early of
 # tile x tile cells (align.cpp:205), 0.39 at the reference's 320 / 120.  Nothing else is counted: no wavefront
 # skew, no loads, no traceback walk, no chain bookkeeping -- those are what `frac` is there to expose.
 def floor_slots_per_cell(linear, tile, early):
-    score, pointer = (7, 7) if linear else (11, 11)
+    score, pointer = (6, 4) if linear else (11, 11)
     window = (min(early, tile) / tile) ** 2
     return (score + pointer * window) / 2.0, {"score_ops_per_cell_pair": score, "pointer_ops_per_cell_pair": pointer,
                                               "pointer_window_fraction": round(window, 4)}

@@ -181,7 +181,7 @@ template <int CW, int QN, int LANES>
 __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                                int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                                const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
-                                               int &nst, int v0)
+                                               int &nst, int v0, const uint32_t *ws_all)
 {
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     constexpr uint32_t kM = 3u, kI = 2u, kD = 1u;               // align.h:23 numbering, as the pass tags them
@@ -192,6 +192,7 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
     LdsByte *ra = (LdsByte *)(rrow + (R - 1) * rstride);
     LdsByte *qa = (LdsByte *)(qrow + (Q - 1));
     LdsByte *cache = (LdsByte *)scratch;
+    const uint32_t ws_off = (uint32_t)((const char *)ws - (const char *)ws_all);   // the workspace is under 4 GB (engine)
     int nis = 0, njs = 0;                                       // minus the ref / query steps taken
     uint32_t cur = 0;
     TbRegion<CW> rg;
@@ -204,7 +205,7 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
 #ifdef GACT_STAMPS
         struct Acc { unsigned long long &sum, t0; __device__ ~Acc() { sum += __builtin_amdgcn_s_memtime() - t0; } } acc_{rf_clk, __builtin_amdgcn_s_memtime()};
 #endif
-        tb_refill_oct<CW, QN, LANES>(ws, scratch, l, c, k, rg);
+        tb_refill_oct<CW, QN, LANES>(ws_all, ws_off, scratch, l, c, k, rg);
         off0 = 4 * (-8 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
     };
@@ -214,11 +215,13 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
         return (w >> (((~(uint32_t)k & 7u) * 2u) | (((uint32_t)c & 1u) << 4))) & 3u;
     };
     // the three column scores in VGPRs (a select between kp's fields themselves is turned into an indexed load
-    // from the kernel argument segment, one memory round trip per step)
+    // from the kernel argument segment, one memory round trip per step).  s_nop: two wait states between the
+    // v_readfirstlane_b32 that writes the SGPR and the VALU instruction that reads it -- inside an asm statement the
+    // compiler does not place them
     int v = v0, v_gap, v_mism, v_match;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v_gap) : "s"(__builtin_amdgcn_readfirstlane(kp.ext)));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v_mism) : "s"(__builtin_amdgcn_readfirstlane(kp.mismatch)));
-    asm volatile("v_mov_b32 %0, %1" : "=v"(v_match) : "s"(__builtin_amdgcn_readfirstlane(kp.match)));
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_gap) : "s"(__builtin_amdgcn_readfirstlane(kp.ext)));
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_mism) : "s"(__builtin_amdgcn_readfirstlane(kp.mismatch)));
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_match) : "s"(__builtin_amdgcn_readfirstlane(kp.match)));
     uint32_t rbase = 0, qbase = 0;                              // bases of the current cell
     if (R >= 1 && Q >= 1 && early > 0) {
         refill(l0, c0, k0);
@@ -284,11 +287,11 @@ template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup, bool COMPACT = f
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
-                                           int &query_steps, int &nst, int v0 = 0)
+                                           int &query_steps, int &nst, int v0 = 0, const uint32_t *ws_all = nullptr)
 {
     if constexpr (FMT == 3) {
         walk_chain_lin<CW, QN, LANES>(ws, scratch, R, Q, l0, c0, k0, early, rrow, rstride, qrow, kp, wk, ref_steps,
-                                      query_steps, nst, v0);
+                                      query_steps, nst, v0, ws_all);
         return;
     }
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000

@@ -505,41 +505,39 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
 // The same for the linear-gap pass's words (FMT 3, gact_lin.hpp: eight columns per uint4, QN uint4 per lane and
 // flush block): 2 lanes x 2 flush blocks x 2 column octets = 8 uint4.  Nine adjacent columns always lie in two
 // octets; lane l0-1 caches its last two.
+// Written for few instructions (a refill runs at the walker's pace, one instruction per 8-10 clocks): the workspace
+// is addressed as ws_all + a 32-bit byte offset (ws_off = the tile's own), a lane's four loads are one offset plus
+// immediates (block and octet strides fit the instruction's offset field).
 template <int CW, int QN, int LANES>
-__device__ __forceinline__ void tb_refill_oct(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
-                                              TbRegion<CW> &rg)
+__device__ __forceinline__ void tb_refill_oct(const uint32_t *ws_all, uint32_t ws_off, uint32_t *scratch, int l0, int c0,
+                                              int k0, TbRegion<CW> &rg)
 {
-    static_assert(QN >= 2 && CW > 8, "two column octets per lane at least");
+    static_assert(QN >= 2 && CW > 8 && ((CW - 9) >> 3) + 1 <= QN - 1, "two column octets per lane at least; octet qbase0 + 1 exists");
+    constexpr int kOct = 16 * LANES, kBlk = 16 * QN * LANES;       // byte strides of a column octet, of a flush block
+    static_assert(kBlk + kOct < 4096, "immediate offsets");
     rg.l0 = l0;
-    rg.qbase0 = imax(c0 - kTbSpan, 0) >> 3;
-    const u32x4 *base = reinterpret_cast<const u32x4 *>(ws);
-    const u32x4 *addr[8];
-#pragma unroll
-    for (int sl = 0; sl < 2; sl++) {
-        const int k_anchor = k0 - sl;
-        const int fb = imax((k_anchor >> 3) - 1, 0);
-        rg.fbase[sl] = fb;
-        const int lane = imax(l0 - sl, 0);
-        const int ob = sl ? QN - 2 : rg.qbase0;
-#pragma unroll
-        for (int lev = 0; lev < 2; lev++)
-#pragma unroll
-            for (int oq = 0; oq < 2; oq++)
-                addr[(sl * 2 + lev) * 2 + oq] = ws_quad_addr<QN, LANES, false>(base, fb + lev, imin(ob + oq, QN - 1), lane);
-    }
+    rg.qbase0 = imax(c0 - kTbSpan, 0) >> 3;                        // nine adjacent columns lie in octets qbase0, qbase0 + 1
+    rg.fbase[0] = imax((k0 >> 3) - 1, 0);
+    rg.fbase[1] = imax(((k0 - 1) >> 3) - 1, 0);
+    const uint32_t a0 = ws_off + (uint32_t)(rg.fbase[0] * kBlk + rg.qbase0 * kOct + l0 * 16);
+    const uint32_t a1 = ws_off + (uint32_t)(rg.fbase[1] * kBlk + (QN - 2) * kOct + imax(l0 - 1, 0) * 16);
     u32x4 r[8];
-#pragma unroll
-    for (int g = 0; g < 2; g++)
-        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                     "global_load_dwordx4 %1, %5, off sc1\n\t"
-                     "global_load_dwordx4 %2, %6, off sc1\n\t"
-                     "global_load_dwordx4 %3, %7, off sc1"
-                     : "=&v"(r[4 * g]), "=&v"(r[4 * g + 1]), "=&v"(r[4 * g + 2]), "=&v"(r[4 * g + 3])
-                     : "v"(addr[4 * g]), "v"(addr[4 * g + 1]), "v"(addr[4 * g + 2]), "v"(addr[4 * g + 3])
-                     : "memory");
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-                 :: "memory");
+    // (s_nop: the base may have just been written by a VALU instruction -- a v_readlane_b32 out of a spill lane --
+    // and a memory instruction must not read such an SGPR for five wait states; the compiler's hazard recogniser
+    // does not look inside this statement)
+    asm volatile("s_nop 4\n\t"
+                 "global_load_dwordx4 %0, %8, %10 sc1\n\t"
+                 "global_load_dwordx4 %1, %8, %10 offset:%11 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, %10 offset:%12 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, %10 offset:%13 sc1\n\t"
+                 "global_load_dwordx4 %4, %9, %10 sc1\n\t"
+                 "global_load_dwordx4 %5, %9, %10 offset:%11 sc1\n\t"
+                 "global_load_dwordx4 %6, %9, %10 offset:%12 sc1\n\t"
+                 "global_load_dwordx4 %7, %9, %10 offset:%13 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+                 : "v"(a0), "v"(a1), "s"(ws_all), "i"(kOct), "i"(kBlk), "i"(kBlk + kOct)
+                 : "memory");
     u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
 #pragma unroll
     for (int n = 0; n < 8; n++) dst[n] = r[n];

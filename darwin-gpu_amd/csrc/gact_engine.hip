@@ -326,8 +326,10 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
     if (e->seed16) {
         const int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
-        auto k16 = raw ? gact::seed_p16_kernel<C, true> : (e->lin && C == 20) ? gact::seed_p16_kernel<C, false, true>
-                                                                              : gact::seed_p16_kernel<C, false>;
+        auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
+        if constexpr (C == 20) {                     // the linear-gap seed pass exists for the 20-column geometry only
+            if (!raw && e->lin) k16 = gact::seed_p16_kernel<C, false, true>;
+        }
         hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
                            kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
                            same_file, sl.overlaps.p, queues(sl), sl.d_ws);
@@ -418,7 +420,8 @@ template <int C> int seed_occupancy_blocks(int *out)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::seed_p16_kernel<C, true>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::seed_p16_kernel<C, false>, gact::kBlockThreads, 0));
     int c = b;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::seed_p16_kernel<C, false, true>, gact::kBlockThreads, 0));
+    if constexpr (C == 20)
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::seed_p16_kernel<C, false, true>, gact::kBlockThreads, 0));
     *out = std::max(1, std::min(a, std::min(b, c)));
     return 0;
 }
@@ -559,6 +562,11 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     const size_t groups = (size_t)std::max(e->grid_blocks, e->lin_grid_blocks) * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
     e->ws_words_total = groups * gact::kSlots * (size_t)e->kp.ws_words;    // two tiles per group in the p16 kernel
 
+    // (the linear-gap walker addresses the workspace with 32-bit byte offsets, gact_device.hpp tb_refill_oct)
+    if ((e->ws_words_total + 64) * sizeof(uint32_t) >= (1ull << 32)) {
+        gact_hip_destroy(e);
+        return fail(GACT_HIP_EINVAL, "pointer workspace of %zu MiB per slot: over 4 GiB", e->ws_words_total * 4 >> 20);
+    }
     e->slots.resize(p->n_slots);
     for (auto &sl : e->slots) {
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||

@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t andn_or(uint32_t a, uint32_t b, uint32_t c)
 __device__ __forceinline__ uint32_t vconst(uint32_t s)
 {
     uint32_t r;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(s));
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(r) : "s"(s));     // (wait states: s may come out of a spill lane)
     return r;
 }
 
@@ -63,6 +63,12 @@ __host__ inline bool p16_lin_ok(int tile, int match, int mismatch, int open, int
            4 * ((long long)match * (tile + 2) + (long long)(-ext) * steps) + 3 <= 30000 && match - ext <= 63;
 }
 
+__device__ __forceinline__ uint32_t pk_mad4v(uint32_t a, uint32_t v_c)     // a * 4 + c (wrapping halves), c in a VGPR
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(v_c));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_ashr2(uint32_t a)
 {
     uint32_t r;
@@ -190,7 +196,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         Z1 += gv; Z24 += g4v;
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
         // lane 15's region-1 column enters region 2 scaled and tagged 3
-        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4(H1, kc.c3)));
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4v(H1, c3v)));
         uint32_t U[CT];
         upper_all(U, true, Z24);
         Hdiag1 = Hl1; Hdiag2 = Hl2;
@@ -219,10 +225,10 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
 #undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
-        for (int c = C1; c < CT; c++) G[c] = pk_mad4(G[c], kc.c3);
-        H2 = pk_mad4(H2, kc.c3);
-        Hdiag2 = pk_mad4(Hdiag2, kc.c3);
-        Z24 = pk_mad4(Z2, kc.c3);
+        for (int c = C1; c < CT; c++) G[c] = pk_mad4v(G[c], c3v);
+        H2 = pk_mad4v(H2, c3v);
+        Hdiag2 = pk_mad4v(Hdiag2, c3v);
+        Z24 = pk_mad4v(Z2, c3v);
         rb2 = rb2 << 2; rb2b = rb2b << 2;               // the row already fetched: bonus times four
     };
 
@@ -381,10 +387,10 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 #undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
-        for (int c = 0; c < C; c++) G[c] = pk_mad4(G[c], kc.c3);
-        G_last = pk_mad4(G_last, kc.c3);
-        Hdiag = pk_mad4(Hdiag, kc.c3);
-        Z4 = pk_mad4(Z, kc.c3);
+        for (int c = 0; c < C; c++) G[c] = pk_mad4v(G[c], c3v);
+        G_last = pk_mad4v(G_last, c3v);
+        Hdiag = pk_mad4v(Hdiag, c3v);
+        Z4 = pk_mad4v(Z, c3v);
         Z8 = Z4 + Z4;
         lutA <<= 2; lutB <<= 2;
     };

@@ -897,7 +897,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
                 walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, LANES, L::kWalkCompact>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
-                                                           query_steps, nst, h ? v0_h[1] : v0_h[0]);
+                                                           query_steps, nst, h ? v0_h[1] : v0_h[0], ws_all);
             }
         }
         GACT_STAMP(t_f);
@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
                 // (FMT 3 walkers start from the score of their cell: the arg-max)
                 walk_chain<C, LIN ? 3 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
                                                   i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
-                                                  s.phase, kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0]);
+                                                  s.phase, kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0], ws_all);
             }
         }
         // ---- consume; a chain whose first tile is done belongs to the main launch

@@ -71,6 +71,10 @@ __host__ inline bool p16_scoring_ok(int tile, int match, int mismatch, int open,
            ext >= -4000 && open - ext > kNegInf16 + 64 && match - mismatch <= 127;
 }
 
+// (the _s forms take a wave-uniform constant.  Its operand is a VGPR all the same: the compiler's hazard recogniser
+// does not look inside an asm statement, and an SGPR that has just come out of a spill lane -- v_readlane_b32, a VALU
+// write -- must not be read by the next two VALU instructions; the copy into the VGPR is the compiler's own
+// instruction and gets its wait states)
 #define GACT_PK2(name, op)                                                                        \
     __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b)                               \
     {                                                                                             \
@@ -81,7 +85,7 @@ __host__ inline bool p16_scoring_ok(int tile, int match, int mismatch, int open,
     __device__ __forceinline__ uint32_t name##_s(uint32_t a, uint32_t s)                           \
     {                                                                                             \
         uint32_t r;                                                                               \
-        asm(op " %0, %1, %2" : "=v"(r) : "v"(a), "s"(s));                                         \
+        asm(op " %0, %1, %2" : "=v"(r) : "v"(a), "v"(s));                                         \
         return r;                                                                                 \
     }
 GACT_PK2(pk_add, "v_pk_add_i16")
@@ -99,7 +103,7 @@ __device__ __forceinline__ uint32_t pk_max0(uint32_t a)
 __device__ __forceinline__ uint32_t pk_mad_s(uint32_t a, uint32_t s, uint32_t c)
 {
     uint32_t r;
-    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(s), "v"(c));
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(s), "v"(c));
     return r;
 }
 
@@ -173,7 +177,7 @@ struct P16Best { int best[2], bi[2], bj[2]; };
 __device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t vmask, uint32_t s_or)      // (a & vmask) | s_or
 {
     uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(vmask), "s"(s_or));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(vmask), "v"(s_or));
     return r;
 }
 __device__ __forceinline__ uint32_t pk_lshr2(uint32_t a)
@@ -191,7 +195,7 @@ __device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t pk_mad4(uint32_t a, uint32_t s_c)      // a * 4 + c (wrapping halves)
 {
     uint32_t r;
-    asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "s"(s_c));
+    asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(s_c));
     return r;
 }
 

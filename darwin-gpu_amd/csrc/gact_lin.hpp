@@ -85,7 +85,7 @@ template <int CW> struct LinWords {
 };
 // acc[c]: the codes of column c, tile A in the low half-word, tile B in the high one
 template <int NW, int LANES, class Fix>
-__device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *qA, uint4 *qB, Fix fix)
+__device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *qA, uint4 *qB, Fix fix, const bool store = true)
 {
     constexpr int QD = (NW + 3) / 4;
     uint32_t wa[QD * 4], wb[QD * 4];
@@ -94,6 +94,7 @@ __device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *
         wa[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x05040100u)) : 0u;
         wb[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x07060302u)) : 0u;
     }
+    if (!store) return;          // a lane whose columns no walk can reach (uniform layout, non-first tiles)
 #pragma unroll
     for (int q = 0; q < QD; q++) {
         qA[q * LANES] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
@@ -272,9 +273,12 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
                                                 const uint32_t (&qb)[C],
                                                 const int T_end, const int tB,
                                                 uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
-                                                const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb)
+                                                const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb,
+                                                const int col_from)
 {
     constexpr int NW = LinWords<C>::kWords, QD = LinWords<C>::kUint4;
+    // col_from: first column (1-based) a walk can reach in either tile: lanes left of it keep their words
+    const bool store = AMAX || gl * C + C >= col_from;
     static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
     const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), onev = vconst(kc.one),
@@ -427,7 +431,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     while (t + 7 <= T_end) {                     // whole blocks of eight steps + flush (see dp_pass_lin_split)
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
-        lin_flush<NW, LANES>(acc, qA, qB, [](uint32_t w) { return w; });
+        lin_flush<NW, LANES>(acc, qA, qB, [](uint32_t w) { return w; }, store);
         qA += QD * LANES;
         qB += QD * LANES;
         if (AMAX) fold(k - 8);
@@ -459,7 +463,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     }
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
-        lin_flush<NW, LANES>(acc, qA, qB, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); });
+        lin_flush<NW, LANES>(acc, qA, qB, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); }, store);
     }
     if (AMAX) return 0;
     // H[R][Q]: slot cq of the lane that owns column Q, at the row of the last step; drift taken off
@@ -480,7 +484,7 @@ struct WideLayoutLin : UniformLayout<10, 32, true> {
     {
         static_assert(!RAW, "the linear-gap pass reads 2-bit sets");
         return dp_pass_lin<10, 32, false>(kc, gl, ref16, qb, T_end, tB, wsA, wsB, (imax(pt.Q[0], 1) - 1) % 10,
-                                          (imax(pt.Q[1], 1) - 1) % 10, nullptr, nullptr);
+                                          (imax(pt.Q[1], 1) - 1) % 10, nullptr, nullptr, pt.col_from);
     }
     __device__ static int fin_lane(int Q) { return (imax(Q, 1) - 1) / 10; }
 };

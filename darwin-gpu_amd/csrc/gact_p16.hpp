@@ -506,6 +506,7 @@ struct PairTile {
     bool reverse[kSlots];
     int64_t rp0[kSlots], qp0[kSlots];
     int comp[kSlots];
+    int col_from;            // first DP column (1-based) a non-first tile's walk can reach, the smaller of the two tiles'
 };
 
 template <int C, bool RAW, int LANES = kGroup>
@@ -846,6 +847,8 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         const int reach1 = have[1] ? tB_h[1] + (T_end - Tend_h[1]) : 0x7fffffff;
         const int tB = wave_min_groups<LANES>(imin(reach0, reach1));
         // (a layout whose walker wants H[R][Q] from the pass delays every tile all the way: last row = last step)
+        // the walk starts in column Q and stops after `early` query steps (align.cpp:205)
+        pt.col_from = imax(imin(have[0] ? pt.Q[0] : 0x7fff, have[1] ? pt.Q[1] : 0x7fff) - kp.early, 0);
         pt.shift[0] = have[0] ? (L::kEndAligned ? T_end - Tend_h[0] : imax(0, tB - tB_h[0])) : 0;
         pt.shift[1] = have[1] ? (L::kEndAligned ? T_end - Tend_h[1] : imax(0, tB - tB_h[1])) : 0;
 
@@ -942,7 +945,8 @@ template <int C, int LANES, bool AMAX>
 __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int gl, const uint16_t *__restrict__ ref16,
                                                 const uint32_t (&qb)[C], const int T_end, const int tB,
                                                 uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
-                                                const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb);
+                                                const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb,
+                                                const int col_from = 0);
 
 // ---------------------------------------------------------------------------
 // Packed seed launch: the first tile(s) of every candidate (arg-max, pointers of the

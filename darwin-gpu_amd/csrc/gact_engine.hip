@@ -179,6 +179,7 @@ struct gact_hip_engine {
     bool static_prio = false;   // GACT_HIP_STATIC_PRIO: fixed thresholds instead of the ranking (read once, at create)
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
+    int seed_lin_grid_blocks = 0;       // ... of its linear-gap form (3)
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
     gact::P16Consts kc;
     hipDeviceProp_t prop;
@@ -325,10 +326,13 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     kp.prio_bases[1] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : rank16;
     // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
     if (e->seed16) {
-        const int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
+        int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
         auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
         if constexpr (C == 20) {                     // the linear-gap seed pass exists for the 20-column geometry only
-            if (!raw && e->lin) k16 = gact::seed_p16_kernel<C, false, true>;
+            if (!raw && e->lin) {
+                k16 = gact::seed_p16_kernel<C, false, true>;
+                blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_lin_grid_blocks));
+            }
         }
         hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
                            kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
@@ -414,7 +418,7 @@ int lin_occupancy_blocks(int *out)
     return 0;
 }
 
-template <int C> int seed_occupancy_blocks(int *out)
+template <int C> int seed_occupancy_blocks(int *out, int *out_lin)
 {
     int a = 0, b = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::seed_p16_kernel<C, true>, gact::kBlockThreads, 0));
@@ -422,7 +426,8 @@ template <int C> int seed_occupancy_blocks(int *out)
     int c = b;
     if constexpr (C == 20)
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::seed_p16_kernel<C, false, true>, gact::kBlockThreads, 0));
-    *out = std::max(1, std::min(a, std::min(b, c)));
+    *out = std::max(1, std::min(a, b));
+    *out_lin = std::max(1, c);          // the linear-gap seed kernel fits three waves per SIMD
     return 0;
 }
 
@@ -548,11 +553,12 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     if (rc) { delete e; return rc; }
     e->grid_blocks = e->blocks_per_cu * e->prop.multiProcessorCount;
     {
-        int sb = 0;
-        rc = (e->C == 20) ? seed_occupancy_blocks<20>(&sb) : seed_occupancy_blocks<32>(&sb);
+        int sb = 0, sbl = 0;
+        rc = (e->C == 20) ? seed_occupancy_blocks<20>(&sb, &sbl) : seed_occupancy_blocks<32>(&sb, &sbl);
         if (rc) { delete e; return rc; }
         // the workspace is sized for grid_blocks groups
         e->seed_grid_blocks = std::min(sb * e->prop.multiProcessorCount, e->grid_blocks);
+        e->seed_lin_grid_blocks = std::min(sbl * e->prop.multiProcessorCount, e->grid_blocks);
     }
     {
         int lb = 0;

@@ -954,7 +954,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 // (ChainQueues) exactly as the int32 seed launch does (extend_kernel, seed_mode).
 // Needs p16_argmax_ok on top of p16_scoring_ok.  LIN: linear gap scoring on 2-bit sets (gact_lin.hpp).
 template <int C, bool RAW, bool LIN = false>
-__global__ __launch_bounds__(kBlockThreads, 2) void seed_p16_kernel(
+__global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     const gact_candidate *__restrict__ cands, int first_cand, int n, int rc_from,
     int same_file, gact_overlap *__restrict__ out, ChainQueues cq,

@@ -210,9 +210,9 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
         off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
     };
     auto fetch = [&](int l, int c, int k) {
-        const uint32_t at = (uint32_t)((2 * c & ~3) + (int)(((uint32_t)k >> 3) << 5) + (l == rg.l0 ? off0 : off1));
-        const uint32_t w = *(LdsWord *)(cache + at);
-        return (w >> (((~(uint32_t)k & 7u) * 2u) | (((uint32_t)c & 1u) << 4))) & 3u;
+        const uint32_t row = ((uint32_t)k >> 3 << 5) + (uint32_t)(l == rg.l0 ? off0 : off1);
+        const uint32_t w = *(LdsWord *)(cache + (((uint32_t)c >> 1 << 2) + row));
+        return __builtin_amdgcn_ubfe(w, (((uint32_t)c & 1u) << 4) + 14u - (((uint32_t)k & 7u) << 1), 2u);
     };
     // the three column scores in VGPRs (a select between kp's fields themselves is turned into an indexed load
     // from the kernel argument segment, one memory round trip per step).  s_nop: two wait states between the
@@ -223,12 +223,14 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
     asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_mism) : "s"(__builtin_amdgcn_readfirstlane(kp.mismatch)));
     asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_match) : "s"(__builtin_amdgcn_readfirstlane(kp.match)));
     uint32_t rbase = 0, qbase = 0;                              // bases of the current cell
+    bool go = false;
     if (R >= 1 && Q >= 1 && early > 0) {
         refill(l0, c0, k0);
-        cur = v == 0 ? 0u : fetch(l0, c0, k0);
+        cur = fetch(l0, c0, k0);
+        go = v != 0;
         rbase = ra[0]; qbase = qa[0];
     }
-    for (int it = 0; cur != 0; it++) {
+    for (int it = 0; go; it++) {
         // ---- one alignment column (gact.cpp:115-130 / :176-191 and :202-209): its score comes off v.  With
         //      gap_open == gap_extend that running sum is also all the rescoring of gact.cpp:197-210 needs
         const bool diag = cur == kM;
@@ -245,11 +247,10 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
         if ((it & 7) == 7) refill(l, c, k);
         // the op and the bases of the cell just entered: three LDS reads in flight together.  The op is the next
         // state whatever the move was (see above); ZERO is only asked for after a diagonal move (align.cpp:211-212
-        // against :219, :225)
-        const uint32_t code = fetch(l, c, k);
+        // against :219, :225); the step limit and the borders: align.cpp:205, :101-107
+        cur = fetch(l, c, k);
         rbase = ra[nis * rstride]; qbase = qa[njs];
-        const uint32_t nxt = (diag && v == 0) ? 0u : code;
-        cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
+        go = !((diag && v == 0) || nis <= nlim_i || njs <= nlim_j);
     }
 #ifdef GACT_STAMPS
     if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_refill_clocks, rf_clk);

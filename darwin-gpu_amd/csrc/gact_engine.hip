@@ -177,6 +177,7 @@ struct gact_hip_engine {
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool static_prio = false;   // GACT_HIP_STATIC_PRIO: fixed thresholds instead of the ranking (read once, at create)
+    int rank16 = (12 << 8) | 8; // GACT_HIP_RANK16: the ranking's thresholds in sixteenths of the longest running chain, hi << 8 | mid
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
     int seed_lin_grid_blocks = 0;       // ... of its linear-gap form (3)
@@ -322,7 +323,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     // GACT_HIP_STATIC_PRIO: thirds of the longest possible chain instead of the ranking against what is running
     const bool static_prio = e->static_prio;
     kp.prio_bases[0] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(longest / 3, 0x7fffffff) : 0;
-    const int rank16 = (12 << 8) | 8;                // above 3/4 of the longest running chain: priority 2, above 1/2: 1
+    const int rank16 = e->rank16;                    // above 3/4 of the longest running chain: priority 2, above 1/2: 1
     kp.prio_bases[1] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : rank16;
     // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
     if (e->seed16) {
@@ -532,6 +533,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
+    if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
     e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
     if (const char *v = getenv("GACT_HIP_WIDE_BLOCKS_PER_CU")) e->wide_blocks_per_cu = atoi(v);
     e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;

@@ -72,9 +72,10 @@ def test_gact_entry_point(oracle, tmp_path):
     assert got == [w.strip() for w in want]
 
 
-@pytest.mark.parametrize("threads", [1, 3])
+@pytest.mark.parametrize("threads", [1, 3, 8])
 def test_driver_end_to_end(oracle, tmp_path, threads):
-    """FASTA + params.cfg + candidates -> darwin.<t>.out, `sort | uniq` equal to the CPU path (README:25)"""
+    """FASTA + params.cfg + candidates -> darwin.<t>.out, `sort | uniq` equal to the CPU path (README:25); 8 feeder
+    threads is BASELINE config 2 as written (darwin.cpp:619-629: one GPU_storage / one engine slot per thread)"""
     from gact_amd import synth
     rs = synth.simulate_reads(30000, n_reads=20, seed=71, mean_len=5000, sd_len=1200, min_len=800, max_len=9000)
     cf, cr = synth.synth_candidates(rs, seed=72, min_overlap=300)

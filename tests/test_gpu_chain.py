@@ -166,3 +166,59 @@ def test_chain_pacbio_shape(oracle):
     cf, cr = synth.synth_candidates(rs, seed=42)
     n = _run(rs, cf, cr, oracle)
     assert n > 300
+
+
+def _edited_copy(rng, src, every=(120, 420), run=(8, 64), point=0.03, alphabet=b"ACGT"):
+    """src with runs of bases deleted / inserted every few hundred bases (long INSERT and DELETE stretches in the
+    traceback, crossing column octets, lanes and flush blocks of the pointer words) and a few point errors"""
+    out, i = [], 0
+    nxt = int(rng.integers(*every))
+    while i < len(src):
+        if i >= nxt:
+            n = int(rng.integers(*run))
+            if rng.random() < 0.5:
+                i += n                                                   # deletion
+            else:
+                out.extend(rng.choice(list(alphabet), n).tolist())      # insertion
+            nxt = i + int(rng.integers(*every))
+            continue
+        b = int(src[i])
+        if rng.random() < point:
+            b = int(rng.choice(list(alphabet)))
+        out.append(b)
+        i += 1
+    return np.array(out, dtype=np.uint8)
+
+
+@pytest.mark.parametrize("alphabet", [b"ACGT", b"AC"])
+def test_chain_long_gap_runs(oracle, alphabet):
+    """overlaps whose alignments hold insertions and deletions of 8-64 bases (and, on a two-letter alphabet, ties
+    between the three moves nearly everywhere): what the flag-less walk of the linear-gap kernels has to get right
+    over many consecutive INSERT / DELETE states, and the affine kernels' open/extend flags"""
+    from gact_amd import synth
+    rng = np.random.default_rng(20261004)
+    genome = rng.choice(list(alphabet), 9000).astype(np.uint8)
+    rs = synth.ReadSet()
+    rs.genome = genome
+    spans = [(0, 6000), (400, 6400), (1500, 8000), (2500, 9000), (100, 3000), (3000, 7000)]
+    for n, (a, b) in enumerate(spans):
+        rs.reads.append(_edited_copy(rng, genome[a:b], alphabet=alphabet) if n else genome[a:b].copy())
+        rs.names.append("L%d_%d_%d" % (n, a, b - a))
+    cands = []
+    for r in range(len(spans)):
+        for q in range(len(spans)):
+            if r == q:
+                continue
+            lo, hi = max(spans[r][0], spans[q][0]), min(spans[r][1], spans[q][1])
+            if hi - lo < 600:
+                continue
+            for g in (lo + 150, (lo + hi) // 2, hi - 150):
+                # the same genome position in both reads, give or take what the edits moved
+                rp = min(max(g - spans[r][0], 1), len(rs.reads[r]) - 1)
+                qp = min(max(g - spans[q][0] + int(rng.integers(-40, 40)), 1), len(rs.reads[q]) - 1)
+                cands.append((r, q, rp, qp))
+    cf = np.array(cands, dtype=synth.CAND_DTYPE)
+    n = _run(rs, cf, cf[:0], oracle)
+    n += _run(rs, cf, cf[:0], oracle, scoring=(2, -3, -3, -3))
+    n += _run(rs, cf, cf[:0], oracle, scoring=(1, -1, -2, -1))
+    assert n == 3 * len(cf) and len(cf) > 60

@@ -284,7 +284,7 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
 // byte stride.  (l0, c0, k0) = lane, column-in-lane and stored step of the start cell
 // (R, Q) in the pass's layout; CW columns per lane, QN column quads stored per lane.
 //
-template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup, bool COMPACT = false>
+template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
@@ -308,7 +308,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
-        tb_refill_at<CW, QN, LANES, COMPACT>(ws, scratch, l, c, k, rg);
+        tb_refill_at<CW, QN, LANES>(ws, scratch, l, c, k, rg);
         off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
     };

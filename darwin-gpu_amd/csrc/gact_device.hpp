@@ -441,28 +441,17 @@ template <int CW> struct TbRegion {
     int qbase0;          // first cached column quad of lane l0 (lane l0-1 always caches its last three)
 };
 
-// Workspace layout of one flush block (8 stored steps of a tile).  Plain: [quad 0..QN-1][lane] uint4, a quad = the
-// pointer words of four adjacent columns.  COMPACT (CW % 4 == 1: the last quad holds one column only): the full
-// quads first, then that column's words as one dword per lane -- (QN-1) * LANES uint4 + LANES dwords, nothing
-// written for columns that do not exist (13 columns: 52 instead of 64 bytes per lane and flush).
-template <int QN, int LANES, bool COMPACT> struct WsBlock {
-    static constexpr int kUint4 = COMPACT ? (QN - 1) * LANES + LANES / 4 : QN * LANES;     // block stride in uint4
-};
-// address a uint4 load of quad q is issued at; for the compact quad it starts at the lane's own dword (element 0 is
-// the wanted word, elements 1..3 belong to the next lanes and are not looked at: c & 3 == 0 there)
-template <int QN, int LANES, bool COMPACT>
+// Workspace layout of one flush block (8 stored steps of a tile): [quad 0..QN-1][lane] uint4, a quad = the pointer
+// words of four adjacent columns (eight in the linear-gap pass's format, below).
+template <int QN, int LANES>
 __device__ __forceinline__ const u32x4 *ws_quad_addr(const u32x4 *base, int blk, int q, int lane)
 {
-    const u32x4 *bb = base + blk * WsBlock<QN, LANES, COMPACT>::kUint4;
-    if (!COMPACT) return bb + q * LANES + lane;
-    const u32x4 *full = bb + q * LANES + lane;
-    const u32x4 *last = reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(bb + (QN - 1) * LANES) + lane);
-    return q < QN - 1 ? full : last;
+    return base + (blk * QN + q) * LANES + lane;
 }
 
 // anchor cell given as (lane l0, column-in-lane c0, stored step k0 = i + l0 - tB)
 // CW = columns per lane, QN = 16-byte column quads stored per lane and flush block
-template <int CW, int QN = CW / 4, int LANES = kGroup, bool COMPACT = false>
+template <int CW, int QN = CW / 4, int LANES = kGroup>
 __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
                                              TbRegion<CW> &rg)
 {
@@ -481,7 +470,7 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
         for (int lev = 0; lev < 2; lev++)
 #pragma unroll
             for (int qq = 0; qq < 3; qq++)
-                addr[(sl * 2 + lev) * 3 + qq] = ws_quad_addr<QN, LANES, COMPACT>(base, fb + lev, imin(qb + qq, QN - 1), lane);
+                addr[(sl * 2 + lev) * 3 + qq] = ws_quad_addr<QN, LANES>(base, fb + lev, imin(qb + qq, QN - 1), lane);
     }
     u32x4 r[12];
 #pragma unroll

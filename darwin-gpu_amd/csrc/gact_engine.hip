@@ -582,8 +582,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
             hipEventCreate(&sl.ev_mid) != hipSuccess ||
             hipMalloc((void **)&sl.d_counter, kCounterInts * sizeof(int)) != hipSuccess ||
             hipMalloc((void **)&sl.d_flags, sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&sl.d_ws, (e->ws_words_total + 64) * sizeof(uint32_t)) != hipSuccess) {     // + slack: a walker's
-                                                                        // uint4 load of a compact last column reads 12 bytes past it
+            hipMalloc((void **)&sl.d_ws, (e->ws_words_total + 64) * sizeof(uint32_t)) != hipSuccess) {     // (+ slack)
             gact_hip_destroy(e);
             return fail(GACT_HIP_ENOMEM, "slot allocation failed (workspace %zu MiB per slot)",
                         e->ws_words_total * 4 >> 20);

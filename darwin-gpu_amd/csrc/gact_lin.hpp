@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t pk_ashr2(uint32_t a)
 
 // Pointer words of this pass (walk_chain's FMT 3): two bits per cell, the op code alone.  A half-word holds eight
 // stored steps of one column (first step on top), a dword two adjacent columns (the even one low), a uint4 eight
-// columns; a flush block is [uint4 n][lane], n < kUint4 (WsBlock<kUint4, LANES, false>, gact_device.hpp).
+// columns; a flush block is [uint4 n][lane], n < kUint4 (ws_quad_addr, gact_device.hpp).
 template <int CW> struct LinWords {
     static constexpr int kWords = (CW + 1) / 2;          // dwords per lane, tile and flush
     static constexpr int kUint4 = (kWords + 3) / 4;

@@ -705,7 +705,6 @@ template <int C, int LANES = kGroup, bool TAG = false> struct UniformLayout {
     static constexpr int kWalkCols = C, kWalkQuads = G::kQuads, kWalkFmt = TAG ? 2 : 1;   // for the walker
     static constexpr int kRow0 = LANES;                           // ref stream entry of (delay 0, row 1)
     static constexpr bool kEndAligned = false;                    // tiles are delayed no more than the pointer start asks
-    static constexpr bool kWalkCompact = false;                   // plain flush-block layout (gact_device.hpp, WsBlock)
     __device__ static int fin_lane(int Q) { (void)Q; return 0; }
     // register budget: 32 columns per lane need a whole SIMD's file
     static constexpr int kBlocksPerCu = C <= 20 ? 3 : 1;
@@ -902,7 +901,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 const uint8_t *qrow = q8 + h * G::kTileMax;
                 int l0, c0, k0;
                 L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
-                walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, LANES, L::kWalkCompact>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
+                walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, LANES>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
                                                            query_steps, nst, h ? v0_h[1] : v0_h[0], ws_all);
             }

@@ -355,7 +355,6 @@ template <int C1, int C2, bool TAG = false> struct SplitLayout {
     static constexpr int kRow0 = G::kRow0;
     static constexpr int kBlocksPerCu = 3;
     static constexpr bool kEndAligned = false;
-    static constexpr bool kWalkCompact = false;
     __device__ static int fin_lane(int Q) { (void)Q; return 0; }
     __device__ static int last_step(int R, int Q) { return split_last_step<C2>(R, Q); }
     __device__ static int first_pointer_step(int R, int Q, int early) { return split_first_pointer_step<C2>(R, Q, early); }

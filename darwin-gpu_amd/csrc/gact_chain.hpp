@@ -138,7 +138,10 @@ __device__ __forceinline__ bool chain_first_tile(ChainState &s, const KParams &k
 }
 
 #ifdef GACT_STAMPS
-__device__ unsigned long long g_refill_clocks;      // diagnostic build: shader clocks spent in the walker's region refills
+// diagnostic build, with -DGACT_STAMPS_REFILL on top: shader clocks spent in the walker's region refills.  Each
+// reading of the clock is a scalar memory round trip of its own (~1 k clocks): the sum is an upper bound that is
+// mostly the measurement, and it lengthens the walk it is taken in -- off unless asked for.
+__device__ unsigned long long g_refill_clocks;
 #endif
 
 // running rescoring state of one candidate while its states stream by
@@ -197,12 +200,12 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
     uint32_t cur = 0;
     TbRegion<CW> rg;
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
-#ifdef GACT_STAMPS
+#ifdef GACT_STAMPS_REFILL
     unsigned long long rf_clk = 0;
 #endif
     // region cache: dword (c >> 1) + 8 * (k >> 3) of a lane's two cached blocks x two cached octets
     auto refill = [&](int l, int c, int k) {
-#ifdef GACT_STAMPS
+#ifdef GACT_STAMPS_REFILL
         struct Acc { unsigned long long &sum, t0; __device__ ~Acc() { sum += __builtin_amdgcn_s_memtime() - t0; } } acc_{rf_clk, __builtin_amdgcn_s_memtime()};
 #endif
         tb_refill_oct<CW, QN, LANES>(ws_all, ws_off, scratch, l, c, k, rg);
@@ -252,7 +255,7 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
         rbase = ra[nis * rstride]; qbase = qa[njs];
         go = !((diag && v == 0) || nis <= nlim_i || njs <= nlim_j);
     }
-#ifdef GACT_STAMPS
+#ifdef GACT_STAMPS_REFILL
     if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_refill_clocks, rf_clk);
 #endif
     ref_steps = -nis; query_steps = -njs;

@@ -1003,7 +1003,7 @@ int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
     unsigned long long rf = 0, zero = 0;
     HIP_TRY(hipMemcpyFromSymbol(&rf, HIP_SYMBOL(gact::g_refill_clocks), sizeof rf));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_refill_clocks), &zero, sizeof zero));
-    if (y[6]) printf("  walker region refills: %llu clocks/iter\n", rf / y[6]);
+    if (y[6] && rf) printf("  walker region refills (upper bound, -DGACT_STAMPS_REFILL): %llu clocks/iter\n", rf / y[6]);
     return 0;
 }
 #endif

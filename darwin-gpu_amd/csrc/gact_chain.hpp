@@ -414,20 +414,12 @@ __device__ __forceinline__ void chain_advance(ChainState &s, bool stop, const Sc
 // 0..15 tiles one class each, 16..47 in fours, 48..111 in eights, 112..607 in sixteens, longer in one.  (With
 // everything beyond 112 tiles in one class, the 50-100 kb reads of the ONT-shape workload -- chains of up to 500
 // tiles -- were popped in no particular order, and a 500-tile chain could start last.)
-#ifndef GACT_AB_BUCKETS32
 constexpr int kBuckets = 64;
 __host__ __device__ constexpr int length_class(int tiles)      // ascending with the length, 0 .. kBuckets-1
 {
     return tiles < 16 ? (tiles < 0 ? 0 : tiles) : tiles < 48 ? 16 + (tiles - 16) / 4 : tiles < 112 ? 24 + (tiles - 48) / 8
          : tiles < 608 ? 32 + (tiles - 112) / 16 : 63;
 }
-#else
-constexpr int kBuckets = 32;
-__host__ __device__ constexpr int length_class(int tiles)
-{
-    return tiles < 16 ? (tiles < 0 ? 0 : tiles) : tiles < 48 ? 16 + (tiles - 16) / 4 : tiles < 112 ? 24 + (tiles - 48) / 8 : 31;
-}
-#endif
 struct ChainQueues {
     int *pop_seed;               // next candidate index for the seed launch
     int *bucket_count;           // [kBuckets] candidates handed to the main launch, bucket 0 = longest

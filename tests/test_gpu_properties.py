@@ -105,7 +105,7 @@ def test_revcomp_on_device_equals_uploaded_set(oracle):
     reads[2][10:40] = np.frombuffer(bytes(reads[2][10:40]).lower(), dtype=np.uint8)
     _, cr = synth.synth_candidates(rs, seed=92, min_overlap=300)
     assert len(cr) > 20
-    recs = []
+    recs, stats = [], []
     for derive in (False, True):
         eng = engine.Engine()
         eng.upload_seqs(engine.SET_REF, reads)
@@ -115,7 +115,21 @@ def test_revcomp_on_device_equals_uploaded_set(oracle):
         else:
             eng.upload_seqs(engine.SET_QUERY_RC, [synth.revcomp(r) for r in reads])
         recs.append(eng.extend(cr, complement=True))
+        stats.append(eng.last_run_stats())
         eng.close()
+    # ... and both are the oracle's records (so that a difference names the run that is wrong)
+    cat = np.concatenate(reads)
+    offs = np.zeros(len(reads) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    want, _ = oracle.gact_many(cat, offs, np.concatenate([synth.revcomp(r) for r in reads]), offs, cr, complement=True,
+                               same_file=True, n_threads=8)
+    for name in ("ab", "ae", "bb", "be", "score", "emitted", "first_tile_score", "n_tiles", "cells"):
+        for which, got in enumerate(recs):
+            if not np.array_equal(got[name], want[name]):
+                k = int(np.flatnonzero(got[name] != want[name])[0])
+                raise AssertionError("%s set: field %s of candidate %d %s:\n hip    %s\n oracle %s\n other  %s\n stats %s" %
+                                     ("derived" if which else "uploaded", name, k, cr[k], got[k], want[k],
+                                      recs[1 - which][k], stats[which]))
     for name in recs[0].dtype.names:
         assert np.array_equal(recs[0][name], recs[1][name]), name
     eng = engine.Engine()

@@ -1,36 +1,38 @@
 // gact_lin.hpp -- the packed-int16 chain pass for LINEAR gap scoring: gap_open == gap_extend == mismatch =: g
 // (the reference's own params.cfg: +1 / -1 / -1 / -1), 2-bit read sets.  Same cells, same results as
-// dp_pass_p16s / dp_pass_p16 -- fewer instructions per cell: 7 instead of 11 per cell pair for the scores,
-// 14 instead of 22 where pointers are made.
+// dp_pass_p16s / dp_pass_p16 -- fewer instructions per cell: 6 instead of 11 per cell pair for the scores,
+// 10 instead of 22 where pointers are made, and pointers of 2 bits per cell instead of 4.
 //
-// 1. Row drift.  Every value of DP row i is kept as X + beta_i with beta_i = -i * g (it grows by |g| per row).
-//    In that frame the recurrence of align.cpp:134-160 loses three additions per cell:
-//      I[i][j] = max(M[i-1][j] + open, I[i-1][j] + ext)   ->  I' = max(M'_up, I'_up)            (open == ext == g)
-//      D[i][j] = max(M[i][j-1] + open, D[i][j-1] + ext)   ->  D' = max(M'_left, D'_left) + g    (same row, same frame)
-//      M[i][j] = max(H[i-1][j-1] + sub, 0)                ->  M' = max(H'_diag + (sub - g), Z)  Z = beta_i: the zero level
-//    and with A := max(M, I), B := max(M, D) -- two of the three maxima H = max(M, I, D) is made of anyway --
-//      I' = A'_up,   D' = B'_left + g,   H' = max(A', D'):
-//    per cell pair perm, add, max (M) | max (A) | sub (D), max (B), max (H) = 7 instructions, and two registers of
-//    state per column slot (H and A of the previous row) instead of three.
+// 1. H alone.  The reference keeps M, I, D (align.cpp:134-160): I[i][j] = max(M, I)[i-1][j] + g.  That differs from
+//    H[i-1][j] + g only where D is the strict maximum at (i-1, j), and then
+//      H[i-1][j] + g = D[i-1][j] + g <= H[i-1][j-1] + 2g <= H[i-1][j-1] + mismatch <= M[i][j]:
+//    the difference never reaches H[i][j], nor the choice between M, I and D there (M wins a tie, align.cpp:162-164).
+//    The same for D.  So one value per cell is carried,
+//      H[i][j] = max(M, 0, H[i-1][j] + g, H[i][j-1] + g),        M = H[i-1][j-1] + sub,
+//    and every H, every op and every arg-max is the reference's.
+// 2. Row drift.  Every value of DP row i is kept as X + beta_i with beta_i = -i * g (it grows by |g| per row):
+//    H[i-1][j] + g is then H'_up as it stands, the zero level is Z = beta_i, and M' = H'_diag + (sub - g) where
 //    sub - g is 0 for a mismatch (mismatch == g) and match - g otherwise: the non-negative byte the look-up word of
-//    dp_pass_p16 already holds, so no bias rides on H any more.  The drift is tied to the step, not to the
-//    tile's row number (rows in front of row 1 are virtual and behave like row 0, gact_device.hpp), so two tiles
-//    with different start delays share it.  -INF never has gap_extend added to it here.
-// 2. Tagged pointers (as dp_pass_p16s, TAG): scores times four, the two low bits say where a value came from.
-//      A'' = max(M'' tagged 3, I'' tagged 2)              next row: low bits 3: the insertion was opened, 2: it goes on
-//      B'' = max(M'' tagged 3, D'' tagged 1)              next column: low bits 3: opened, 1: goes on
-//      H'' = max(A'', D'' tagged 1)                       the op in align.h:23 numbering (M3 I2 D1)
-//    flags = (A''_up ^ (B''_left + 4g)) & 3 = {bit 0: insertion goes on, bit 1: deletion goes on}.
-//    H == 0 shows as op 3 like MATCH (M'' is clamped to the zero level tagged 3): ZERO is left to the walker, which
-//    carries the score of the cell it stands on (walk_chain, FMT 3).  It needs H of the start cell (R, Q): every
-//    tile of a wave is delayed so that its last row falls on the wave's last step, and the value is simply what
-//    the lane of column Q holds when the loop ends.
-// 3. Instruction classes.  tools/issue_probe.hip (profiles/r02/issue_rate_probe.json): with three waves on a SIMD
-//    v_add_u32 / v_sub_u32 / v_and_b32 / v_or_b32 / v_xor_b32 / v_bitop3_b32 on VGPR operands issue every 1.9
-//    cycles, v_pk_*, v_max_*, v_perm_b32, v_and_or_b32, v_mad_*, DPP moves and anything with an SGPR operand every
-//    3.2-3.4.  So the frame is shifted up (kLinBase) until every value is a positive int16: the packed additions
-//    then cannot carry or borrow across the half-words and run as plain 32-bit v_add_u32 / v_sub_u32, -INF becomes 0,
-//    the re-taggings are written so that the compiler takes v_bitop3_b32, and the constants sit in VGPRs.
+//    dp_pass_p16 already holds.  Per cell pair: perm, add | max Z, max H'_up | sub, max = 6 instructions, one
+//    register of state per column slot.  The drift is tied to the step, not to the tile's row number (rows in
+//    front of row 1 are virtual and behave like row 0, gact_device.hpp), so two tiles with different start delays
+//    share it.
+// 3. Op-only pointers.  Inside the traceback window the scores are times four and the two low bits say where a value
+//    came from -- M 3, H_up 2, H_left 1: the numbering of align.h:23, and the tie order of align.cpp:162-164 is the
+//    order of the tags:
+//      H'' = max(M'' | 3, Z'', H''_up - 1, H''_left - (4|g| + 2)),     op = H'' & 3,     stored: G = H'' | 3
+//    -- 10 instructions per pair with the two that shift the op into its column's half-word.  No open / extend flags
+//    are made: the walker does not need them (walk_chain_lin, gact_chain.hpp: with these scorings the next state of
+//    the traceback is the op of the cell it enters).  H == 0 shows as op 3 like MATCH (M'' is clamped to the zero
+//    level tagged 3): ZERO is left to the walker too, which carries the score of the cell it stands on.  It needs H
+//    of the start cell (R, Q): every tile of a wave is delayed so that its last row falls on the wave's last step,
+//    and the value is simply what the lane of column Q holds when the loop ends.
+// 4. Instruction classes.  tools/issue_probe.hip (profiles/r02/issue_rate_probe.json): with three waves on a SIMD
+//    v_add_u32 / v_sub_u32 / v_and_b32 / v_or_b32 on VGPR operands issue every 1.9 cycles, v_pk_*, v_max_*,
+//    v_perm_b32, v_mad_*, DPP moves and anything with an SGPR operand every 3.2-3.4.  So the frame is shifted up
+//    (lin_base) until every value is a positive int16: the packed additions then cannot carry or borrow across the
+//    half-words and run as plain 32-bit v_add_u32 / v_sub_u32, the re-taggings are a subtraction each, and the
+//    constants sit in VGPRs.
 #pragma once
 
 #include "gact_p16s.hpp"
@@ -40,13 +42,6 @@ namespace gact {
 // zero level of lane 0 before step 1: above 31 lanes' worth of drift plus one gap, so nothing ever goes below |g|
 __host__ __device__ constexpr int lin_base(int g) { return 40 * (-g) + 8; }
 // a wave-uniform constant the compiler must keep in a VGPR (an SGPR operand would put the instruction in the slow class)
-// (a & ~b) | c on the fast logic path (the compiler folds the pattern into v_and_or_b32, which is not)
-__device__ __forceinline__ uint32_t andn_or(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xdc" : "=v"(r) : "v"(a), "v"(c), "v"(b));
-    return r;
-}
 __device__ __forceinline__ uint32_t vconst(uint32_t s)
 {
     uint32_t r;

@@ -12,6 +12,7 @@ import oracle_py
 from gact_amd import engine, synth
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+RAW_ONLY = os.environ.get("STRESS_RAW_ONLY")      # every read set with N (and lower case): the raw-byte kernels only
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 orc = oracle_py.Oracle()
 FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
@@ -34,9 +35,13 @@ for it in range(n_cfg):
     if rng.random() < 0.5:                       # linear gaps (open == extend == mismatch): the drifted pass
         g = -int(rng.choice([0, 1, 1, 1, 2, 3, 5, 9]))
         scoring = (match, g, g, g)
-    n_frac = float(rng.choice([0.0, 0.0, 0.004]))
+    n_frac = float(rng.choice([0.0, 0.0, 0.004])) if RAW_ONLY is None else 0.004
     rs = synth.simulate_reads(int(rng.integers(6000, 20000)), n_reads=int(rng.integers(6, 16)), seed=int(rng.integers(1 << 30)),
                               mean_len=int(rng.integers(1500, 5000)), sd_len=900, min_len=200, max_len=9000, n_frac=n_frac)
+    if n_frac > 0 and rng.random() < 0.5:       # soft-masked stretches: lower case compares unequal to upper (align.cpp:134)
+        for r in rs.reads:
+            a = int(rng.integers(0, max(1, len(r) - 40)))
+            r[a:a + 30] = np.frombuffer(bytes(r[a:a + 30]).lower(), dtype=np.uint8)
     cf, cr = synth.synth_candidates(rs, seed=int(rng.integers(1 << 30)), min_overlap=150,
                                     false_frac=float(rng.choice([0.0, 0.3])))
     cat, offs = rs.concat()

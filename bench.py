@@ -159,6 +159,8 @@ def main():
     kernel_ms = []
 
     rec_buf = np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE)      # the job's output buffer, owned by the caller
+    if nf + nr:
+        eng.register_output(rec_buf, slot=0)                     # page-locked once, explicitly: fetches are one DMA
 
     gather = None
     if use_dist:
@@ -193,10 +195,11 @@ def main():
     dt = time.perf_counter() - t0
     if rec is None:          # distributed run: the engine's full records of this rank, for the cell count and the parity gate
         rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
-        if gathered is not None:                         # what rank 0 gathered of itself is what its engine holds
-            mine = gdist.lines_from_overlaps(rec)
-            if gathered[0].tobytes() != mine.tobytes():
-                raise SystemExit("bench.py: gathered records differ from the engine's")
+        # what rank 0 gathered of EVERY rank is what that rank's engine holds (checksums, one all_gather)
+        try:
+            gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
+        except RuntimeError as err:
+            raise SystemExit("bench.py: %s" % err)
     rf, rr = rec[:nf], rec[nf:]
 
     my_cells = int(rf["cells"].sum() + rr["cells"].sum())

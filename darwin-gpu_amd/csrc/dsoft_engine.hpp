@@ -245,6 +245,7 @@ int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int3
     HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
     sl.n_cands = n;
+    sl.cands_epoch = e->sets_epoch;          // the list is valid for these sets only (check_candidate_range)
     if (query_ms) HIP_TRY(hipEventElapsedTime(query_ms, sl.ev0, sl.ev1));
     return 0;
 }

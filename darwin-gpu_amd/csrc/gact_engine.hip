@@ -118,10 +118,11 @@ struct Slot {
     int *d_flags = nullptr;
     gact_overlap *h_records = nullptr;  // pinned staging for candidates_fetch (pageable D2H is staged by the runtime
     size_t h_records_cap = 0;           // in small chunks: 0.2-0.9 ms for 3.7 MB; pinned + memcpy: 0.25 ms)
-    // a caller that fetches into the same buffer again and again (a feeder thread's result array) gets it
-    // page-locked the second time it is seen: the records then go straight there, no staging copy
-    void *last_out = nullptr, *reg_out = nullptr;
+    // a caller-owned output buffer page-locked on request (gact_hip_register_output): fetches whose destination lies
+    // inside it go straight there, no staging copy.  Never registered behind the caller's back.
+    void *reg_out = nullptr;
     size_t reg_bytes = 0;
+    int64_t cands_epoch = -1;           // sets_epoch at which the device filter made this slot's list (-1: uploaded list)
     SeqSet inline_ref, inline_query;   // Align_Batch_GPU-style inline tiles
 };
 
@@ -177,6 +178,7 @@ struct gact_hip_engine {
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool static_prio = false;   // GACT_HIP_STATIC_PRIO: fixed thresholds instead of the ranking (read once, at create)
+    uint32_t poison = 0;        // GACT_HIP_POISON_WS=<seed>: the workspace is filled with a seeded pattern before every launch
     int rank16 = (12 << 8) | 8; // GACT_HIP_RANK16: the ranking's thresholds in sixteenths of the longest running chain, hi << 8 | mid
     bool seed16 = false;        // first tiles on the packed seed kernel too (arg-max keys fit)
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
@@ -208,6 +210,16 @@ int check_slot(gact_hip_engine *e, int slot)
     if (!e) return fail(GACT_HIP_EINVAL, "engine is NULL");
     if (slot < 0 || slot >= (int)e->slots.size())
         return fail(GACT_HIP_EINVAL, "slot %d out of range [0,%d)", slot, (int)e->slots.size());
+    return 0;
+}
+
+// GACT_HIP_POISON_WS: seeded garbage over the slot's whole traceback workspace (poison_kernel)
+int poison_ws(gact_hip_engine *e, Slot &sl, uint32_t salt)
+{
+    if (!e->poison) return 0;
+    hipLaunchKernelGGL(gact::poison_kernel, dim3(e->prop.multiProcessorCount * 8), dim3(256), 0, sl.stream, sl.d_ws,
+                       e->ws_words_total + 64, e->poison * 0x01000193u + salt);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -347,6 +359,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     sl.two_phase = e->p16;
     if (e->p16) {
         HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
+        { int prc = poison_ws(e, sl, 0x5bd1e995u); if (prc) return prc; }      // the main launch reads nothing the seed launch stored
         // fewer chains than the narrow layouts have tile slots: the launch lasts as long as its longest chain, so
         // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
         const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
@@ -465,6 +478,7 @@ int run_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &qf, 
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     HIP_TRY(hipMemcpyAsync(sl.tiles.p, tiles, (size_t)n * sizeof(gact_tile), hipMemcpyHostToDevice, sl.stream));
     HIP_TRY(hipMemsetAsync(sl.results.p, 0, (size_t)n * sizeof(gact_tile_result), sl.stream));
+    { int prc = poison_ws(e, sl, 0x2545f491u); if (prc) return prc; }
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
     int rc = (e->C == 20) ? launch_tiles<20>(e, sl, rs, qf, qr, n, states_stride)
                           : launch_tiles<32>(e, sl, rs, qf, qr, n, states_stride);
@@ -534,6 +548,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
     if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
+    if (const char *v = getenv("GACT_HIP_POISON_WS")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
     e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
     if (const char *v = getenv("GACT_HIP_WIDE_BLOCKS_PER_CU")) e->wide_blocks_per_cu = atoi(v);
     e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;
@@ -562,19 +577,24 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         e->seed_grid_blocks = std::min(sb * e->prop.multiProcessorCount, e->grid_blocks);
         e->seed_lin_grid_blocks = std::min(sbl * e->prop.multiProcessorCount, e->grid_blocks);
     }
-    {
+    e->lin_grid_blocks = e->grid_blocks;
+    auto ws_words_for = [&](int blocks) {
+        const size_t groups = (size_t)blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
+        return groups * gact::kSlots * (size_t)e->kp.ws_words;             // two tiles per group in the p16 kernel
+    };
+    if (e->lin) {
+        // the linear-gap split launch has its own occupancy, and its walker addresses the workspace with 32-bit byte
+        // offsets (gact_device.hpp tb_refill_oct): engines that never run it are sized without it, and one whose
+        // workspace would pass 4 GiB runs the affine passes instead
         int lb = 0;
         if ((rc = lin_occupancy_blocks(&lb))) { delete e; return rc; }
         e->lin_grid_blocks = std::max(e->grid_blocks, lb * e->prop.multiProcessorCount);
+        if ((ws_words_for(e->lin_grid_blocks) + 64) * sizeof(uint32_t) >= (1ull << 32)) {
+            e->lin = false;
+            e->lin_grid_blocks = e->grid_blocks;
+        }
     }
-    const size_t groups = (size_t)std::max(e->grid_blocks, e->lin_grid_blocks) * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
-    e->ws_words_total = groups * gact::kSlots * (size_t)e->kp.ws_words;    // two tiles per group in the p16 kernel
-
-    // (the linear-gap walker addresses the workspace with 32-bit byte offsets, gact_device.hpp tb_refill_oct)
-    if ((e->ws_words_total + 64) * sizeof(uint32_t) >= (1ull << 32)) {
-        gact_hip_destroy(e);
-        return fail(GACT_HIP_EINVAL, "pointer workspace of %zu MiB per slot: over 4 GiB", e->ws_words_total * 4 >> 20);
-    }
+    e->ws_words_total = ws_words_for(std::max(e->grid_blocks, e->lin_grid_blocks));
     e->slots.resize(p->n_slots);
     for (auto &sl : e->slots) {
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -586,6 +606,11 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
             gact_hip_destroy(e);
             return fail(GACT_HIP_ENOMEM, "slot allocation failed (workspace %zu MiB per slot)",
                         e->ws_words_total * 4 >> 20);
+        }
+        // a fresh workspace never shows what an earlier engine of this process left in the same memory
+        if (hipMemsetAsync(sl.d_ws, 0xA5, (e->ws_words_total + 64) * sizeof(uint32_t), sl.stream) != hipSuccess) {
+            gact_hip_destroy(e);
+            return fail(GACT_HIP_EDEVICE, "workspace initialisation failed");
         }
     }
     *out = e;
@@ -765,6 +790,7 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
     sl.n_cands = 0;
     sl.h_cands.assign(cands, cands + n);
     sl.checked_key[0] = -1;
+    sl.cands_epoch = -1;
     if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, cands, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
                                   sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
@@ -776,7 +802,13 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
 // (index >= rc_from: GACT_SET_QUERY_RC); remembered, so that repeated runs of one range check once
 static int check_candidate_range(gact_hip_engine *e, Slot &sl, int32_t first, int32_t n, int32_t rc_from)
 {
-    if (sl.h_cands.empty()) return 0;                 // made by the device filter from these very sets
+    if (sl.h_cands.empty()) {
+        // made by the device filter: valid for the sets it was made from, and for those only
+        if (n > 0 && sl.cands_epoch != e->sets_epoch)
+            return fail(GACT_HIP_EINVAL, "candidates_run: a read set was uploaded after the device filter made this slot's "
+                                         "candidates; run gact_hip_dsoft_query again");
+        return 0;
+    }
     const int64_t key[4] = {first, n, rc_from, e->sets_epoch};
     if (!memcmp(key, sl.checked_key, sizeof key)) return 0;
     const SeqSet &rs = e->sets[GACT_SET_REF];
@@ -810,6 +842,7 @@ int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, i
         return fail(GACT_HIP_EINVAL, "candidates_run: read sets not uploaded");
     if ((rc = check_candidate_range(e, sl, first, n, rc_from))) return rc;
     HIP_TRY(hipMemsetAsync(sl.d_counter, 0, kCounterInts * sizeof(int), sl.stream));
+    if ((rc = poison_ws(e, sl, 0))) return rc;
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
     sl.two_phase = false;
     if (n > 0) {
@@ -842,13 +875,8 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
         return fail(GACT_HIP_EINVAL, "candidates_fetch: bad arguments (slot %d holds %zu candidates)", slot, sl.n_cands);
     if ((rc = set_device(e))) return rc;
     const size_t bytes = (size_t)n * sizeof(gact_overlap);
-    if (n > 0 && out == sl.last_out && (sl.reg_out != out || sl.reg_bytes < bytes)) {
-        if (sl.reg_out) { (void)hipHostUnregister(sl.reg_out); sl.reg_out = nullptr; sl.reg_bytes = 0; }
-        if (hipHostRegister(out, bytes, hipHostRegisterDefault) == hipSuccess) { sl.reg_out = out; sl.reg_bytes = bytes; }
-        else (void)hipGetLastError();
-    }
-    sl.last_out = out;
-    if (n > 0 && sl.reg_out == out && sl.reg_bytes >= bytes) {
+    if (n > 0 && sl.reg_out && (char *)out >= (char *)sl.reg_out &&
+        (char *)out + bytes <= (char *)sl.reg_out + sl.reg_bytes) {
         HIP_TRY(hipMemcpyAsync(out, sl.overlaps.p, bytes, hipMemcpyDeviceToHost, sl.stream));
         HIP_TRY(hipStreamSynchronize(sl.stream));
         return 0;
@@ -867,6 +895,34 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
                                   sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
     if (n && dst != out) memcpy(out, dst, (size_t)n * sizeof(gact_overlap));
+    return 0;
+}
+
+int gact_hip_register_output(gact_hip_engine *e, int slot, void *buf, int64_t bytes)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if (!buf || bytes <= 0) return fail(GACT_HIP_EINVAL, "register_output: bad arguments");
+    if ((rc = set_device(e))) return rc;
+    Slot &sl = e->slots[slot];
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    if (sl.reg_out) { (void)hipHostUnregister(sl.reg_out); (void)hipGetLastError(); sl.reg_out = nullptr; sl.reg_bytes = 0; }
+    HIP_TRY(hipHostRegister(buf, (size_t)bytes, hipHostRegisterDefault));
+    sl.reg_out = buf; sl.reg_bytes = (size_t)bytes;
+    return 0;
+}
+
+int gact_hip_unregister_output(gact_hip_engine *e, int slot)
+{
+    int rc = check_slot(e, slot);
+    if (rc) return rc;
+    if ((rc = set_device(e))) return rc;
+    Slot &sl = e->slots[slot];
+    if (!sl.reg_out) return 0;
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    void *p = sl.reg_out;
+    sl.reg_out = nullptr; sl.reg_bytes = 0;
+    HIP_TRY(hipHostUnregister(p));
     return 0;
 }
 

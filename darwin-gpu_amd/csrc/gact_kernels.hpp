@@ -310,6 +310,20 @@ __global__ void revcomp_kernel(const uint8_t *__restrict__ raw, const int64_t *_
 }
 
 // ---------------------------------------------------------------------------
+// Diagnostic (GACT_HIP_POISON_WS=<seed>): fills the traceback workspace with a seeded pseudo-random pattern in front
+// of every launch, so that a walker reading a pointer word its own pass did not store gets garbage that changes
+// with the seed instead of whatever an earlier tile left there.  Results must not depend on the seed.
+__global__ void poison_kernel(uint32_t *__restrict__ ws, size_t n_words, uint32_t seed)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
+        uint32_t x = (uint32_t)i * 0x9E3779B1u + seed;           // one round of a multiplicative hash per word
+        x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16;
+        ws[i] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // VALU issue-rate probe for the instruction class the packed kernels are made of: 16 independent accumulators,
 // v_pk_max_i16 and v_pk_add_i16 in rotation, nothing else.  gact_hip_measure_valu_rate launches it with eight waves
 // per SIMD: the sustained packed-int16 lane-op rate of this device (tools/issue_probe.hip has the whole table).

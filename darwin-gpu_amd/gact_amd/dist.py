@@ -139,12 +139,36 @@ class RecordGather:
         if self.n_mine:
             self.buf[:self.n_mine].copy_(src[:self.n_mine])
         self.dist.gather(self.buf, self.outs, dst=0)
+        if self.device != "cpu":
+            # the copy out of the engine's record array and the collective are queued on torch's stream; the engine's
+            # next launch (its own non-blocking stream) rewrites that array: every rank waits here, not only rank 0
+            torch.cuda.current_stream().synchronize()
         if self.rank != 0:
             return None
         return [o[:n] for o, n in zip(self.outs, self.counts)]
 
     def to_host(self, parts, dtype):
         return [p.cpu().numpy().reshape(-1).view(dtype) for p in parts]
+
+
+def checksum_lines(lines):
+    """order-sensitive checksum of LINE_DTYPE records (what a rank sent / what rank 0 received from it)"""
+    import zlib
+    return zlib.crc32(np.ascontiguousarray(lines).tobytes())
+
+
+def verify_gathered(torch, dist, my_lines, gathered, rank, world, device):
+    """every rank's own line records against what rank 0 holds of it after the gather: the per-rank checksums
+    travel in one all_gather; rank 0 raises on the first rank whose part differs"""
+    mine = torch.tensor([checksum_lines(my_lines)], dtype=torch.int64, device=device)
+    sums = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(sums, mine)
+    if rank != 0:
+        return True
+    for r in range(world):
+        if checksum_lines(gathered[r]) != int(sums[r].item()):
+            raise RuntimeError("gathered records of rank %d differ from what that rank's engine holds" % r)
+    return True
 
 
 def gather_records(torch, dist, records, rank, world, device):

@@ -176,7 +176,9 @@ def load():
     L.gact_hip_dsoft_query.argtypes = [vp, C.c_int, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     L.gact_hip_candidates_download.argtypes = [vp, C.c_int, i32, vp]
     L.gact_hip_derive_revcomp.argtypes = [vp]
-    for name in ("derive_revcomp", "dsoft_build", "dsoft_query", "candidates_download", "create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
+    L.gact_hip_register_output.argtypes = [vp, C.c_int, vp, C.c_int64]
+    L.gact_hip_unregister_output.argtypes = [vp, C.c_int]
+    for name in ("register_output", "unregister_output", "derive_revcomp", "dsoft_build", "dsoft_query", "candidates_download", "create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
                  "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range", "candidates_run_mixed",
                  "candidates_fetch", "sync", "last_kernel_ms", "last_run_stats", "format_overlap"):
         getattr(L, "gact_hip_" + name).restype = C.c_int
@@ -190,7 +192,8 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_candidates_run_range", "gact_hip_candidates_run_mixed", "gact_hip_candidates_fetch", "gact_hip_sync",
            "gact_hip_last_kernel_ms", "gact_hip_last_run_stats", "gact_hip_device_overlaps", "gact_hip_stream",
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
-           "gact_hip_candidates_download", "gact_hip_derive_revcomp")
+           "gact_hip_candidates_download", "gact_hip_derive_revcomp", "gact_hip_register_output",
+           "gact_hip_unregister_output")
 
 
 class Engine:
@@ -305,6 +308,15 @@ class Engine:
         assert out.dtype == OVERLAP_DTYPE and len(out) >= n and out.flags["C_CONTIGUOUS"]
         self._check(self.L.gact_hip_candidates_fetch(self.h, slot, n, out.ctypes.data))
         return out
+
+    def register_output(self, out, slot=0):
+        """page-locks a caller-owned record array that will be fetched into repeatedly (opt-in; it must outlive the
+        registration)"""
+        assert out.flags["C_CONTIGUOUS"]
+        self._check(self.L.gact_hip_register_output(self.h, slot, out.ctypes.data, out.nbytes))
+
+    def unregister_output(self, slot=0):
+        self._check(self.L.gact_hip_unregister_output(self.h, slot))
 
     def sync(self, slot=0):
         self._check(self.L.gact_hip_sync(self.h, slot))

@@ -190,10 +190,15 @@ int gact_hip_extend_candidates(gact_hip_engine *e, int slot, int32_t n,
  * the inputs already resident in HBM */
 int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const gact_candidate *cands);
 int gact_hip_candidates_run(gact_hip_engine *e, int slot, int32_t n, int complement, int same_file);
-/* fetch: records [0, n) into the caller's buffer.  A buffer that is passed twice in a row is page-locked by the
- * engine (hipHostRegister) so that later fetches go straight into it; it stays registered until another buffer is
- * passed or the engine is destroyed -- keep it alive that long. */
+/* fetch: records [0, n) into the caller's buffer (through the engine's own pinned staging area unless `out` lies
+ * inside a buffer registered with gact_hip_register_output). */
 int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_overlap *out);
+/* Opt-in for a caller that fetches into one long-lived buffer again and again (a feeder thread's result array; the
+ * reference's counterpart is the malloc'd outs_b of cuda_host.cu:67,183-189): page-locks [buf, buf + bytes) so that
+ * fetches into it are one DMA with no staging copy.  One registered buffer per slot; it must stay allocated until
+ * gact_hip_unregister_output (or gact_hip_destroy).  The engine never page-locks caller memory on its own. */
+int gact_hip_register_output(gact_hip_engine *e, int slot, void *buf, int64_t bytes);
+int gact_hip_unregister_output(gact_hip_engine *e, int slot);
 /* runs on candidates [first, first+n) of the uploaded array (multi-GPU shards) */
 int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n,
                                   int complement, int same_file);

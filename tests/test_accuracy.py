@@ -1,9 +1,11 @@
 """CPU suite: the accuracy harness (tools/measure_sensitivity.py, own rewrite of the reference's
-measure_sensitivity_PBSIM.py in its de-novo mode) pinned on committed data: the 16-read FASTA of
-tests/golden/dsoft.json and the lines the REFERENCE's CPU program printed for it (tests/golden/e2e.json).
-The expected counts come from a brute-force restatement of the reference's rules written out below
-(theoretical overlaps :84-106, mirrored lines :129-146, filters :160-175, matching :183-214, ratios :265-270),
-and are pinned as numbers as well."""
+measure_sensitivity_PBSIM.py in its de-novo mode) pinned on what THE REFERENCE SCRIPT ITSELF printed:
+tests/golden/accuracy.json holds, for two sets of output lines over the 16 reads of tests/golden/dsoft.json (the
+67 lines the reference's CPU program printed, and an edited set that trips every filter), the counts and ratios
+measure_sensitivity_PBSIM.py printed when tests/golden/make_accuracy_golden.py ran it (lib2to3-converted, in a
+temporary directory, build container only).  The brute-force restatement of the rules written out below
+(theoretical overlaps :84-106, mirrored lines :129-146, filters :160-175, matching :183-214, ratios :265-270)
+is kept as a second witness."""
 import json
 import os
 import re
@@ -72,3 +74,27 @@ def test_accuracy_harness_pinned(tmp_path):
 
 
 PINNED = (58, 118, 112, 4, 6)
+
+
+def test_accuracy_harness_equals_the_reference_script(tmp_path):
+    """every case of tests/golden/accuracy.json: the numbers the reference's own script printed"""
+    import measure_sensitivity
+    gold = json.load(open(os.path.join(GOLD, "accuracy.json")))
+    assert set(gold["cases"]) >= {"e2e", "perturbed"}
+    fasta = "".join(">%s\nACGT\n" % h for h in gold["headers"])
+    (tmp_path / "reads.fasta").write_text(fasta)
+    for name, case in gold["cases"].items():
+        out = tmp_path / ("%s.out" % name)
+        out.write_text("\n".join(case["lines"]) + "\n")
+        got = measure_sensitivity.measure(str(tmp_path / "reads.fasta"), [str(out)])
+        want = case["expected"]
+        for k in ("theoretical", "kept", "TP", "FN", "FP"):
+            assert got[k] == want[k], (name, k, got, want)
+        assert got["lines"] * 2 == want["heuristic_with_mirrors"]
+        # the script prints six decimals (:269-270)
+        assert abs(got["sensitivity"] - want["sensitivity"]) < 1e-6 and abs(got["specificity"] - want["specificity"]) < 1e-6
+        # ... and the brute-force restatement agrees with both
+        bf = brute_force(fasta, case["lines"])
+        assert {k: bf[k] for k in ("theoretical", "kept", "TP", "FN", "FP")} == {k: want[k] for k in ("theoretical", "kept", "TP", "FN", "FP")}
+    e = gold["cases"]["e2e"]["expected"]
+    assert (e["theoretical"], e["kept"], e["TP"], e["FN"], e["FP"]) == PINNED

@@ -41,6 +41,8 @@ def _worker(rank, world, port, q):
     rr, _ = orc.gact_many(cat, offs, rcat, offs, my_cr, complement=True)
     mine = np.concatenate([rf, rr])
     parts = gdist.gather_records(torch, dist, mine, rank, world, "cpu")
+    # every rank's part as rank 0 received it, against that rank's own records (what bench.py checks at N > 1)
+    gdist.verify_gathered(torch, dist, mine, parts, rank, world, "cpu")
     if rank == 0:
         nf = [len(cf_all[r::world]) for r in range(world)]
         got_f = gdist.undeal([p[:n] for p, n in zip(parts, nf)], len(cf_all))

@@ -141,3 +141,88 @@ def test_config3_pacbio50mb(oracle):
         assert got.tobytes() == w.rec[:w.nf][pick].tobytes()
     finally:
         w.close()
+
+
+def test_config4_one_rank_of_eight(oracle, capsys):
+    """Config 4 (500 MB of ~10 kb PacBio-shape reads, candidate batch sharded over 8 MI355X) as far as
+    one GPU can show it: the workload is built the way `bench.py --gpus 8 --workload pacbio50mb` builds it (eight
+    independent genome blocks, every block's reads resident on every rank, the merged candidate list dealt
+    round-robin), and the shares of two of the eight ranks run here -- rank 0's against the oracle on more than
+    10,000 candidates of both strands (SURVEY 8d's gate), both with the extent, idempotence and shard properties.
+    The reference has nothing to mirror (cuda_host.cu:195 hard-wires device 0); its semantics per candidate are
+    gact.cpp:48-228 as everywhere."""
+    import json
+    from gact_amd import dist as gdist, engine, synth, workload
+    world = 8
+    t = time.time()
+    blocks = []
+    for b in range(world):
+        blk = workload.make_block("pacbio50mb", block=b, candidates="dsoft")
+        blocks.append((blk.rs.reads, blk.cf, blk.cr))
+    reads, cf_all, cr_all = gdist.merge_blocks(blocks)
+    offs = np.zeros(len(reads) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    cat = np.concatenate(reads)
+    rcat = np.concatenate([synth.revcomp(r) for r in reads])
+    rl = np.diff(offs)
+    assert len(reads) == 8 * 5000 and offs[-1] > 400e6                  # ~0.42 Gb of bases, three resident sets
+    assert len(cf_all) + len(cr_all) > 2_000_000
+    build_s = time.time() - t
+    eng = engine.Engine()
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs)
+    eng.upload(engine.SET_QUERY_RC, rcat, offs)
+    lines = []
+    try:
+        for rank in (0, 5):
+            my_cf, my_cr = gdist.deal(cf_all, rank, world), gdist.deal(cr_all, rank, world)
+            nf, nr = len(my_cf), len(my_cr)
+            cands = np.concatenate([my_cf, my_cr])
+            eng.candidates_upload(cands)
+            best = None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                eng.candidates_run_mixed(nf + nr, rc_from=nf)
+                rec = eng.candidates_fetch(nf + nr).copy()
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+                if _ == 0:
+                    first = rec
+                else:                                               # idempotence under the persistent scheduling
+                    assert zlib.crc32(rec.tobytes()) == zlib.crc32(first.tobytes())
+            st = eng.last_run_stats()
+            assert st["layout"] == "packed16-split" and st["linear_gap"]
+            # extents inside the reads of the merged set, strands as dealt
+            assert (rec["n_tiles"] >= 1).all() and (rec["cells"] <= rec["n_tiles"].astype(np.int64) * 320 * 320).all()
+            assert (rec["ab"] >= 0).all() and (rec["ab"] <= rec["ae"]).all() and (rec["ae"] <= rl[rec["ref_id"]]).all()
+            assert (rec["bb"] >= 0).all() and (rec["bb"] <= rec["be"]).all() and (rec["be"] <= rl[rec["query_id"]]).all()
+            assert np.array_equal(rec["comp"], (np.arange(len(rec)) >= nf).astype(np.int32))
+            assert rec["cells"].sum() > 0.8e12 and rec["emitted"].mean() > 0.5
+            stride = 33 if rank == 0 else 331
+            n_checked = 0
+            for comp, sl, qcat in ((False, slice(0, nf), cat), (True, slice(nf, nf + nr), rcat)):
+                c, got = cands[sl][::stride], rec[sl][::stride]
+                want, _ = oracle.gact_many(cat, offs, qcat, offs, c, complement=comp, same_file=True, n_threads=_threads())
+                for f in FIELDS:
+                    if not np.array_equal(got[f], want[f]):
+                        k = int(np.flatnonzero(got[f] != want[f])[0])
+                        raise AssertionError("rank %d: %s differs at %s-strand candidate %d: hip %s, oracle %s" %
+                                             (rank, f, "rc" if comp else "fwd", k * stride, got[k], want[k]))
+                n_checked += len(c)
+            assert n_checked > (10000 if rank == 0 else 1000)
+            lines.append({"config": "4 (one rank of eight on one MI355X)", "workload": "pacbio50mb x 8 blocks", "rank": rank,
+                          "world": world, "reads_resident": len(reads), "bases_resident": int(offs[-1]),
+                          "candidates_all_ranks": int(len(cf_all) + len(cr_all)), "candidates_this_rank": int(nf + nr),
+                          "tiles": int(rec["n_tiles"].sum()), "cells": int(rec["cells"].sum()),
+                          "ms_per_step": round(best * 1e3, 2), "main_ms": round(st["main_ms"], 2),
+                          "seed_ms": round(st["seed_ms"], 2), "gcups_this_rank": round(rec["cells"].sum() / best / 1e9, 1),
+                          "oracle_checked": n_checked, "bit_exact": True, "build_seconds": round(build_s, 1)})
+    finally:
+        eng.close()
+    with capsys.disabled():
+        for ln in lines:
+            print("\nCONFIG4 " + json.dumps(ln))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "config4_one_rank_of_eight.jsonl"), "w") as f:
+        for ln in lines:
+            f.write(json.dumps(ln) + "\n")

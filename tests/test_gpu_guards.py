@@ -81,3 +81,63 @@ def test_filter_index_dies_with_its_reference_set():
     c = eng.candidates_download(nf + nr)
     assert (c["ref_id"] == 0).all()
     eng.close()
+
+
+def test_device_filter_list_dies_with_the_sets_it_was_made_from():
+    """a list made by gact_hip_dsoft_query names reads and positions of the sets of that moment: after any upload
+    candidates_run* refuses it instead of launching on unchecked ids (gact_engine.hip::check_candidate_range)"""
+    from gact_amd import engine, synth
+    eng = engine.Engine()
+    reads = _reads(5, [5000, 4000, 6000, 4500])
+    rc = [synth.revcomp(r) for r in reads]
+    eng.upload_seqs(engine.SET_REF, reads); eng.upload_seqs(engine.SET_QUERY, reads); eng.upload_seqs(engine.SET_QUERY_RC, rc)
+    eng.dsoft_build(engine.DsoftParams(seed_size=10))
+    nf, nr, _ = eng.dsoft_query(0, 4)
+    assert nf + nr > 0
+    eng.candidates_run_mixed(nf + nr, rc_from=nf)
+    first = eng.candidates_fetch(nf + nr).copy()
+    eng.upload_seqs(engine.SET_QUERY, reads[:1])               # fewer, shorter queries: the old ids are out of range
+    with pytest.raises(engine.GactHipError, match="dsoft_query again"):
+        eng.candidates_run_mixed(nf + nr, rc_from=nf)
+    eng.upload_seqs(engine.SET_QUERY, reads)                   # same bytes again: still a different epoch
+    with pytest.raises(engine.GactHipError, match="dsoft_query again"):
+        eng.candidates_run_mixed(nf + nr, rc_from=nf)
+    nf2, nr2, _ = eng.dsoft_query(0, 4)
+    assert (nf2, nr2) == (nf, nr)
+    eng.candidates_run_mixed(nf + nr, rc_from=nf)
+    assert eng.candidates_fetch(nf + nr).tobytes() == first.tobytes()
+    eng.close()
+
+
+def test_registered_output_buffer_is_opt_in():
+    """fetches go through the engine's own pinned staging area unless the caller registered the destination
+    (gact_hip_register_output); a buffer the caller frees and the allocator hands out again is never DMA'd into
+    behind a stale registration, because nothing is registered on the engine's own initiative"""
+    from gact_amd import engine
+    eng = engine.Engine()
+    reads = _reads(6, [4000, 4200, 3900])
+    for which in (engine.SET_REF, engine.SET_QUERY, engine.SET_QUERY_RC):
+        eng.upload_seqs(which, reads)
+    c = np.zeros(64, dtype=engine.CAND_DTYPE)
+    c["ref_id"] = np.arange(64) % 3
+    c["query_id"] = (np.arange(64) + 1) % 3
+    c["ref_pos"] = c["query_pos"] = 1000 + 7 * np.arange(64)
+    eng.candidates_upload(c)
+    eng.candidates_run(64)
+    want = eng.candidates_fetch(64).copy()
+    for _ in range(20):                                       # fresh arrays: same addresses come back from the allocator
+        assert eng.candidates_fetch(64, out=np.empty(64, dtype=engine.OVERLAP_DTYPE)).tobytes() == want.tobytes()
+    big = np.zeros(256, dtype=engine.OVERLAP_DTYPE)
+    eng.register_output(big)
+    for off in (0, 10, 192):                                  # anywhere inside the registered range: direct copy
+        eng.candidates_fetch(64, out=big[off:off + 64])
+        assert big[off:off + 64].tobytes() == want.tobytes()
+    other = np.zeros(64, dtype=engine.OVERLAP_DTYPE)          # outside it: the staging path
+    assert eng.candidates_fetch(64, out=other).tobytes() == want.tobytes()
+    eng.unregister_output()
+    eng.candidates_fetch(64, out=big[:64])
+    assert big[:64].tobytes() == want.tobytes()
+    eng.register_output(big); eng.register_output(other)      # a second registration replaces the first
+    eng.candidates_fetch(64, out=other)
+    assert other.tobytes() == want.tobytes()
+    eng.close()                                               # destroys the registration with the engine

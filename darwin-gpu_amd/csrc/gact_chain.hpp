@@ -264,6 +264,156 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
     // (open == extend: the gap bookkeeping of wk decides nothing)
 }
 
+// ---------------------------------------------------------------------------
+// The look-ahead walker of the linear-gap pointer format: the same walk as walk_chain_lin, by a TEAM of eight lanes.
+//
+// A walker step is a whole wave instruction however few lanes walk, and a step is ~50 dependent instructions and an LDS
+// round trip: ~700 clocks, 213 steps per tile -- 18 % of a wave's time in the split layout, 40 % in the wide one, with
+// two lanes of sixteen (thirty-two) at work.  But the walk is mostly diagonal: a MATCH step is left only where the
+// alignment has an indel (13 % of the columns of the PacBio-shape reads, 8 % of the ONT-shape ones), and along a
+// diagonal nothing depends on the step before except the running score.  So lane m of the team looks at the cell m
+// steps up the diagonal from the walk's cell -- its op, its two bases -- and the team settles how far the MATCH run
+// goes in one iteration:
+//   * cell m can be taken as a MATCH column iff it and every cell before it hold op M and the walk did not stop on
+//     the way: after cell m the score is v - S_m (S_m = the substitution scores of cells 0..m: a count of equal-base
+//     cells among them, from one ballot), the walk stops there iff that is 0 (ZERO, align.cpp:166-168 -- only asked
+//     after a diagonal move) or a step limit / border is reached (align.cpp:205, :101-107);
+//   * the first lane that is not M, or stops, ends the run: n = its index (+1 when
+//     it stops: the stopping cell is processed) MATCH columns are consumed at once, every lane updates the same
+//     state from the same ballots -- no lane-to-lane data movement at all;
+//   * a cell that holds INSERT / DELETE at the head is one gap step, as in walk_chain_lin.
+// Semantics are walk_chain_lin's, step for step (same cells, same order, same stop tests); only how many steps one
+// trip through the loop takes differs.
+// Region cache: rows i-16..i x columns j-16..j of the anchor cell = up to three lanes x three flush blocks x all the
+// lane's column octets = 18 uint4, loaded by the team together (two or three 16-byte loads per lane, one memory round
+// trip) whenever the head has moved more than eight rows or columns from the anchor, so eight cells of look-ahead are
+// always inside.
+constexpr int kLaTeam = 8, kLaSpan = 16, kLaRefill = 8;
+template <int CW, int QN> struct LaRegion {
+    static constexpr int NL = CW >= kLaSpan ? 2 : 3;       // lanes 17 adjacent columns can touch
+    static constexpr int NB = 3;                           // flush blocks 17 adjacent stored steps can touch
+    static constexpr int kUint4 = NL * NB * QN;
+    static_assert(2 * CW >= kLaSpan, "three lanes cover the region");
+    static_assert(kUint4 <= 3 * kLaTeam, "three loads per lane fill the region");
+    static_assert(kUint4 * 4 <= kTbScratchWords, "LDS scratch of a walker");
+    static_assert(kLaRefill + kLaTeam - 1 <= kLaSpan, "eight cells of look-ahead stay inside the region between refills");
+};
+
+template <int CW, int QN, int LANES>
+__device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const bool active, int R, int Q, int l0, int c0, int k0,
+                                                    int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
+                                                    const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
+                                                    int &nst, int v0, const uint32_t *ws, const uint32_t *ws_all)
+{
+    using RG = LaRegion<CW, QN>;
+    constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
+    constexpr uint32_t kM = 3u, kI = 2u;                        // align.h:23 numbering, as the pass tags them
+    constexpr int kOct = 16 * LANES, kBlk = 16 * QN * LANES;    // byte strides of a column octet, of a flush block
+    constexpr int kRow = 16 * QN;                               // bytes of one cached (lane, flush block)
+    const int lane = threadIdx.x & 63, m = lane & (kLaTeam - 1);
+    const uint32_t team_shift = (uint32_t)lane & 56u;
+    auto team_bits = [team_shift](uint64_t mask) { return (uint32_t)(mask >> team_shift) & 0xffu; };
+    const int p0 = l0 * CW + c0, kA = k0 - l0;
+    const int nlim_i = -imin(early, R), nlim_j = -imin(early, Q);
+    typedef __attribute__((address_space(3))) const uint8_t LdsByte;
+    typedef __attribute__((address_space(3))) const uint32_t LdsWord;
+    LdsByte *ra = (LdsByte *)(rrow + (R - 1) * rstride);
+    LdsByte *qa = (LdsByte *)(qrow + (Q - 1));
+    LdsByte *cache = (LdsByte *)scratch;
+    const uint32_t ws_off = (uint32_t)((const char *)ws - (const char *)ws_all);   // the workspace is under 4 GB (engine)
+
+    // this lane's loads of a refill: uint4 n = m, m + 8, m + 16 of the region, n = (slot * NB + block) * QN + octet
+    // (slot s = lane l_anchor - s)
+    int ld_n[3], ld_slot[3], ld_stat[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int n = imin(m + kLaTeam * r, RG::kUint4 - 1);
+        const int slot = n / (RG::NB * QN), rem = n - slot * (RG::NB * QN), blk = rem / QN, oct = rem - blk * QN;
+        ld_n[r] = n; ld_slot[r] = slot; ld_stat[r] = blk * kBlk + oct * kOct;
+    }
+    int la = 0, b0 = 0, b1 = 0, b2 = 0;                         // anchor lane; cache offsets of the three slots
+    auto refill = [&](int l_a, int k_a) {
+        const int f0 = imax((k_a >> 3) - 2, 0), f1 = imax(((k_a - 1) >> 3) - 2, 0), f2 = imax(((k_a - 2) >> 3) - 2, 0);
+        uint32_t a[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int sl = ld_slot[r];
+            const int fb = sl == 0 ? f0 : sl == 1 ? f1 : f2;
+            a[r] = ws_off + (uint32_t)(fb * kBlk + ld_stat[r] + imax(l_a - sl, 0) * 16);
+        }
+        u32x4 q0, q1, q2;
+        // (s_nop: the base may have just been written by a VALU instruction -- a v_readlane_b32 out of a spill lane --
+        // and a memory instruction must not read such an SGPR for five wait states)
+        asm volatile("s_nop 4\n\t"
+                     "global_load_dwordx4 %0, %3, %6 sc1\n\t"
+                     "global_load_dwordx4 %1, %4, %6 sc1\n\t"
+                     "global_load_dwordx4 %2, %5, %6 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(q0), "=&v"(q1), "=&v"(q2)
+                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "s"(ws_all)
+                     : "memory");
+        u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
+        dst[ld_n[0]] = q0; dst[ld_n[1]] = q1; dst[ld_n[2]] = q2;
+        wave_sync();
+        la = l_a;
+        b0 = kRow * (0 * RG::NB - f0); b1 = kRow * (1 * RG::NB - f1); b2 = kRow * (2 * RG::NB - f2);
+    };
+    // the three column scores in VGPRs (see walk_chain_lin)
+    int v = v0, v_gap, v_mism, v_dsub;
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_gap) : "s"(__builtin_amdgcn_readfirstlane(kp.ext)));
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_mism) : "s"(__builtin_amdgcn_readfirstlane(kp.mismatch)));
+    asm volatile("s_nop 1\n\tv_mov_b32 %0, %1" : "=v"(v_dsub) : "s"(__builtin_amdgcn_readfirstlane(kp.match - kp.mismatch)));
+    int nis = 0, njs = 0;                                       // minus the ref / query steps taken (the head cell)
+    int di = 0, dj = 0;                                         // rows / columns the head has moved from the anchor
+    bool go = active && R >= 1 && Q >= 1 && early > 0 && v0 != 0;
+    if (go) refill(l0, k0);
+    const uint32_t below = (2u << m) - 1u;                      // cells 0..m of the diagonal
+    while (go) {
+        // ---- this lane's cell: m steps up the diagonal from the head.  The head is at most kLaRefill rows and columns
+        //      from the anchor here, so the cell is inside the cached region
+        const int ci = nis - m, cj = njs - m;
+        // (a cell beyond the end of the walk may lie outside the tile: keep its addresses inside the stored window)
+        const int p = imax(p0 + cj, 0);
+        const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);
+        const int c = p + __mul24(l, -CW);
+        const int k = imax(kA + l + ci, 0);
+        const int sl = la - l;
+        const uint32_t at = (uint32_t)((sl == 0 ? b0 : sl == 1 ? b1 : b2) + __mul24(k >> 3, kRow) + ((c >> 1) << 2));
+        const uint32_t w = *(LdsWord *)(cache + at);
+        const uint32_t rb = ra[ci * rstride], qb = qa[cj];
+        const uint32_t op = __builtin_amdgcn_ubfe(w, (((uint32_t)c & 1u) << 4) + 14u - (((uint32_t)k & 7u) << 1), 2u);
+        const bool is_m = op == kM;
+        // ---- the run of MATCH columns from the head (align.cpp:210-217, gact.cpp:115-130 / :176-191); written
+        //      without branches: every lane evaluates both kinds of head and selects
+        const uint32_t eq_bits = team_bits(lanes(rb == qb));
+        const int s_m = __mul24(m + 1, v_mism) + __mul24((int)__builtin_popcount(eq_bits & below), v_dsub);
+        const bool stops = is_m & ((v - s_m == 0) | (ci - 1 <= nlim_i) | (cj - 1 <= nlim_j));
+        const uint32_t gap_bits = team_bits(lanes(!is_m)), stop_bits = team_bits(lanes(stops));
+        const uint32_t i_bits = team_bits(lanes(op == kI));
+        // first lane that is not M / that stops; a lane cannot be both, and 8 means none
+        const int e_gap = __builtin_ctz(gap_bits | 0x100u), e_stop = __builtin_ctz(stop_bits | 0x100u);
+        const bool halted = e_stop < e_gap;
+        const int n_run = halted ? e_stop + 1 : e_gap;          // MATCH columns consumed (the stopping cell is one of them)
+        const bool head_m = !(gap_bits & 1u), ins = i_bits & 1u;
+        // one gap column (align.cpp:218-229) when the head is not M: its score comes off v, no ZERO test after it
+        const int n_i = head_m ? n_run : (int)ins, n_j = head_m ? n_run : 1 - (int)ins;
+        const int dv_run = __mul24(n_run, v_mism) + __mul24((int)__builtin_popcount(eq_bits & ((1u << n_run) - 1u)), v_dsub);
+        v -= head_m ? dv_run : v_gap;
+        nis -= n_i; njs -= n_j; di += n_i; dj += n_j;
+        go = head_m ? !halted : !((nis <= nlim_i) | (njs <= nlim_j));
+        if (go && imax(di, dj) > kLaRefill) {
+            const int ph = imax(p0 + njs, 0);
+            const int lh = (int)(__umul24((uint32_t)ph, kMagic) >> 16);
+            refill(lh, imax(kA + lh + nis, 0));
+            di = 0; dj = 0;
+        }
+    }
+    ref_steps = -nis; query_steps = -njs;
+    nst = -nis - njs;                                            // only "were there any columns" is asked (chain_advance)
+    wk.score += v0 - v;                                          // what the columns of this tile scored
+    // (open == extend: the gap bookkeeping of wk decides nothing)
+}
+
 // The chain kernels' walker: traceback (align.cpp:185-230) fused with the rescoring
 // of gact.cpp:197-210, written for few instructions per step -- every step of a
 // walker is a whole wave instruction however few lanes walk, and a tile's walk is

@@ -433,7 +433,7 @@ __device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int 
 // 12 uint4) from the HBM workspace into its own LDS scratch -- all 12 loads in
 // flight at once, one latency per 8 steps -- and the steps in between read LDS.
 constexpr int kTbSpan = 8;
-constexpr int kTbScratchWords = 12 * 4;      // dwords of LDS per walker
+constexpr int kTbScratchWords = 18 * 4;      // dwords of LDS per walker (12 uint4 of tb_refill_at, 18 of the look-ahead walker's region)
 
 template <int CW> struct TbRegion {
     int l0;              // lane of the anchor column

@@ -37,6 +37,11 @@ __device__ unsigned long long g_timeline[4 * 4096];
 #define GACT_ACC(slot, t0, t1)
 #endif
 
+// -DGACT_WALK_SINGLE_LANE=1: the linear-gap format walked by one lane per tile (walk_chain_lin), for A/B measurements
+#ifndef GACT_WALK_SINGLE_LANE
+#define GACT_WALK_SINGLE_LANE 0
+#endif
+
 constexpr int kNegInf16 = -16384;
 constexpr int kSlots = 2;                  // tiles per 16-lane group (low / high half-word)
 
@@ -889,18 +894,27 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         int ref_steps = 0, query_steps = 0, nst = 0;
         ScoreWalk wk;
         wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
+        // (the linear-gap format is walked by a team of eight lanes per tile: the first eight lanes of the tile's half
+        // of the group, gact_chain.hpp walk_chain_lin_team; the other formats by one lane per tile, lanes 0 and 1)
+        constexpr bool kTeamWalk = L::kWalkFmt == 3 && !GACT_WALK_SINGLE_LANE;
+        constexpr int kWalkLanes = kTeamWalk ? LANES / kSlots : 1;         // lane h * kWalkLanes holds the walk's results
         {
-            const int h = w.gl & 1;
-            const bool mine = (w.gl < kSlots) && (h ? have[1] : have[0]);
-            if (mine) {
+            const int h = kTeamWalk ? w.gl / kWalkLanes : (w.gl & 1);
+            const bool mine = (kTeamWalk ? w.gl - h * kWalkLanes < kLaTeam : w.gl < kSlots) && (h ? have[1] : have[0]);
+            const int sh = h ? pt.shift[1] : pt.shift[0];
+            const int Rh = h ? pt.R[1] : pt.R[0], Qh = h ? pt.Q[1] : pt.Q[0];
+            const uint8_t *rrow = ref8 + (L::kRow0 + sh) * 2 + h;
+            const uint8_t *qrow = q8 + h * G::kTileMax;
+            int l0, c0, k0;
+            L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
+            if constexpr (kTeamWalk) {
+                wk.load(st[h]);
+                walk_chain_lin_team<L::kWalkCols, L::kWalkQuads, LANES>(tb_lds[group_in_block][h], mine, Rh, Qh, l0, c0, k0, kp.early,
+                                                                        rrow, 2, qrow, kp, wk, ref_steps, query_steps, nst,
+                                                                        h ? v0_h[1] : v0_h[0], h ? wsB : wsA, ws_all);
+            } else if (mine) {
                 const ChainState &s = st[h];
                 wk.load(s);
-                const int sh = h ? pt.shift[1] : pt.shift[0];
-                const int Rh = h ? pt.R[1] : pt.R[0], Qh = h ? pt.Q[1] : pt.Q[0];
-                const uint8_t *rrow = ref8 + (L::kRow0 + sh) * 2 + h;
-                const uint8_t *qrow = q8 + h * G::kTileMax;
-                int l0, c0, k0;
-                L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
                 walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, LANES>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
                                                            query_steps, nst, h ? v0_h[1] : v0_h[0], ws_all);
@@ -914,7 +928,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 ChainState s = st[h];
                 s.n_tiles++;
                 s.cells += (int64_t)pt.R[h] * pt.Q[h];
-                chain_advance<LANES>(s, false, wk, ref_steps, query_steps, nst, h);
+                chain_advance<LANES>(s, false, wk, ref_steps, query_steps, nst, h * kWalkLanes);
                 wave_sync();
                 if (w.gl == 0) st[h] = s;
             }
@@ -1050,15 +1064,22 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
         int ref_steps = 0, query_steps = 0, nst = 0;
         ScoreWalk wk;
         wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
+        constexpr bool kTeamWalk = LIN && !GACT_WALK_SINGLE_LANE;          // (see extend_p16_kernel)
+        constexpr int kWalkLanes = kTeamWalk ? kGroup / kSlots : 1;
         {
-            const int h = w.gl & 1;
-            const bool mine = (w.gl < kSlots) && !(h ? stop[1] : stop[0]);
+            const int h = kTeamWalk ? w.gl / kWalkLanes : (w.gl & 1);
+            const bool mine = (kTeamWalk || w.gl < kSlots) && !(h ? stop[1] : stop[0]);
             const ChainState &s = st[h];
             wk.load(s);
-            if (mine) {
-                const int i0 = h ? pb.bi[1] : pb.bi[0], j0 = h ? pb.bj[1] : pb.bj[0];
-                const int l0 = (j0 - 1) / C;
-                // (FMT 3 walkers start from the score of their cell: the arg-max)
+            const int i0 = h ? pb.bi[1] : pb.bi[0], j0 = h ? pb.bj[1] : pb.bj[0];
+            const int l0 = (imax(j0, 1) - 1) / C;
+            // (FMT 3 walkers start from the score of their cell: the arg-max)
+            if constexpr (kTeamWalk) {
+                walk_chain_lin_team<C, ((C + 1) / 2 + 3) / 4, kGroup>(tb_lds[group_in_block][h], mine, i0, j0, l0, (j0 - 1) - l0 * C,
+                                                                      i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
+                                                                      kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0],
+                                                                      h ? wsB : wsA, ws_all);
+            } else if (mine) {
                 walk_chain<C, LIN ? 3 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
                                                   i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
                                                   s.phase, kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0], ws_all);
@@ -1069,7 +1090,7 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
         for (int h = 0; h < kSlots; h++) {
             if (have[h]) {
                 ChainState s = st[h];
-                chain_advance(s, stop[h], wk, ref_steps, query_steps, nst, h);
+                chain_advance(s, stop[h], wk, ref_steps, query_steps, nst, h * kWalkLanes);
                 if (!s.first_tile) {
                     if (w.gl == 0) {
                         cq.states[s.cand] = s;

@@ -30,6 +30,7 @@ OPS_PER_CELL = 24            # 11 score + 10 pointer + 3 arg-max i
 # pairs on few waves, not the machine's.
 NOMINAL_LANES_PER_CU_CLK = 128
 ISSUE_CYCLES = 2
+FETCH_SIZE_CORRECTION = 2.0
 
 
 def host_cores():
@@ -76,13 +77,13 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
 # wave64 VALU instruction; the kernels work on int16 pairs, two cells per slot.  Per cell PAIR the recurrence of
 # align.cpp:134-160 needs, in the cheapest formulation known for the scoring in use,
 #   affine gaps (any scoring):          11 ops for the scores, 11 more where traceback pointers are made
-#   linear gaps (open == extend == mismatch, the reference's params.cfg): 6 and 4 more (gact_lin.hpp: H alone,
-#                                                                          op-only pointers)
+#   linear gaps (open == extend == mismatch, the reference's params.cfg): 5 and 4 more (gact_lin.hpp: H alone,
+#                                                 two of its three maxima in one v_pk_maximum3_f16, op-only pointers)
 # and pointers are needed only inside the window a non-first tile's traceback can reach: early x early of
 # tile x tile cells (align.cpp:205), 0.39 at the reference's 320 / 120.  Nothing else is counted: no wavefront
 # skew, no loads, no traceback walk, no chain bookkeeping -- those are what `frac` is there to expose.
 def floor_slots_per_cell(linear, tile, early):
-    score, pointer = (6, 4) if linear else (11, 11)
+    score, pointer = (5, 4) if linear else (11, 11)
     window = (min(early, tile) / tile) ** 2
     return (score + pointer * window) / 2.0, {"score_ops_per_cell_pair": score, "pointer_ops_per_cell_pair": pointer,
                                               "pointer_window_fraction": round(window, 4)}
@@ -99,6 +100,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even at N=1")
+    ap.add_argument("--no-others", action="store_true",
+                    help="skip the other single-GPU configurations (pacbio50mb, ont) that a default N=1 run appends under other_configs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,7 +242,7 @@ def main():
         # issue peak: one wave64 VALU instruction per SIMD per 2 cycles = 128 lane-op slots per CU per clock
         peak_slots = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
         linear = bool(kernel_ms[-1].get("linear_gap"))
-        floor, model = floor_slots_per_cell(linear, 320, 200)
+        floor, model = floor_slots_per_cell(linear, eng.tile_size, eng.tile_size - eng.tile_overlap)
         achieved = floor * main_cells / (k_ms * 1e-3) / 1e12
         pmc = pmc_lookup(args.workload, args.candidates, main_kernel, main_cells)
         executed = traffic = traffic_source = None
@@ -251,14 +254,25 @@ def main():
                         "floor_over_executed": round(floor / slots, 4), "profiled_kernel_ms": pmc["profiled_kernel_ms"],
                         "source": pmc["source"] + " (SQ_INSTS_VALU, GRBM_GUI_ACTIVE of this kernel on this workload; "
                                   "utilisation = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))"}
-            traffic = int((pmc["write_kib"] + pmc["fetch_kib"]) * 1024)
-            traffic_source = pmc["source"] + " (WRITE_SIZE / FETCH_SIZE in separate passes; %.1f GB written + %.1f GB " \
-                "read as reported)" % (pmc["write_kib"] * 1024 / 1e9, pmc["fetch_kib"] * 1024 / 1e9)
+            # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16-byte) streaming reads by 2x -- the walker's
+            # region refills are exactly that -- so the read side is doubled; WRITE_SIZE is taken as reported
+            traffic = int((pmc["write_kib"] + FETCH_SIZE_CORRECTION * pmc["fetch_kib"]) * 1024)
+            traffic_source = pmc["source"] + " (WRITE_SIZE / FETCH_SIZE in separate passes; %.1f GB written as reported + " \
+                "%.1f GB read = %gx the reported FETCH_SIZE, the guide's gfx950 correction for 16-byte reads)" % (
+                    pmc["write_kib"] * 1024 / 1e9, FETCH_SIZE_CORRECTION * pmc["fetch_kib"] * 1024 / 1e9, FETCH_SIZE_CORRECTION)
         roofline = {
-            # integer-VALU roofline.  achieved = algorithmic lane-op slots (model below) x cells of
-            # the main launch / its HIP-event time; peak = the SIMDs' issue rate; frac <= 1 by construction:
-            # frac = (floor / executed slots per cell) x VALU issue utilisation.
-            "bound": "valu", "achieved": round(achieved, 3), "peak": round(peak_slots, 3),
+            # integer-VALU roofline.  The two figures that do not depend on a model of the algorithm
+            # come first: what share of the SIMDs' issue slots the kernel used, and how many lane-op slots it executed
+            # per DP cell (both from the committed PMC pass of this kernel on this workload; null without one).
+            # achieved = algorithmic lane-op slots (model below) x cells of the main launch / its HIP-event time;
+            # peak = the SIMDs' issue rate; frac <= 1 by construction = (floor / executed slots per cell) x utilisation.
+            # The floor is the cheapest formulation KNOWN for the scoring in use and has moved between rounds
+            # (4.87 -> 3.78 -> 3.28 slots per cell): compare rounds on valu_issue_utilisation, executed_slots_per_cell
+            # and survey_24op_int32, not on frac.
+            "bound": "valu",
+            "valu_issue_utilisation": executed["valu_issue_utilisation"] if executed else None,
+            "executed_slots_per_cell": executed["slots_per_cell"] if executed else None,
+            "achieved": round(achieved, 3), "peak": round(peak_slots, 3),
             "unit": "T lane-op slots/s (one lane of one wave64 VALU instruction; int16 pairs: two DP cells per slot)",
             "frac": round(achieved / peak_slots, 4),
             "model": dict(model, slots_per_cell=round(floor, 3), scoring="linear gaps" if linear else "affine gaps"),
@@ -298,9 +312,16 @@ def main():
 
         if not args.no_cpu:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr)
+            out["cpu_baseline"]["reference"] = reference_baseline(reads, my_cf, rf)
+        if world == 1 and not use_dist and not args.no_others and args.workload == "ecoli10x":
+            # the other single-GPU configurations of BASELINE.json, a few steps each, with their own parity gate
+            eng.close()
+            eng = None
+            out["other_configs"] = [side_config(w, args) for w in ("pacbio50mb", "ont")]
         print(json.dumps(out))
         sys.stdout.flush()
-    eng.close()
+    if eng is not None:
+        eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -335,6 +356,88 @@ def cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr):
             "sample": "%d forward-strand candidates of this workload (%d cells, %.1f s), oracle/gact_oracle.c, "
                       "%d threads over contiguous candidate ranges" % (n, cells, dt, threads)}
     return base, {"checked_candidates": int(n + nr), "bit_exact": True}
+
+
+def reference_baseline(reads, my_cf, rf, budget_s=8.0):
+    """The reference AS WRITTEN (oracle/_ref/libdarwin_ref.so = the reference's own align.cpp + gact.cpp compiled
+    unchanged) on a handful of this workload's candidates, one thread (its GACT keeps state in globals): the figure
+    SURVEY.md 8d asks to be quoted next to the port.  Its printed line is compared with the HIP record on the way.
+    Skipped with a note where the prebuilt library is absent."""
+    import numpy as np
+    import oracle_py
+    if not oracle_py.ref_available():
+        return {"value": None, "kind": "reference", "note": "oracle/_ref/libdarwin_ref.so not present on this box"}
+    ref = oracle_py.RefLib()
+    orc = oracle_py.Oracle()
+    # shortest chains first would flatter nothing: take them in list order, emitted ones, until the budget is spent
+    t0 = time.perf_counter()
+    cells = n = 0
+    for k in range(len(my_cf)):
+        if time.perf_counter() - t0 > budget_s:
+            break
+        c, r = my_cf[k], rf[k]
+        if not r["emitted"]:
+            continue
+        line = ref.gact_line(reads[c["ref_id"]].tobytes(), reads[c["query_id"]].tobytes(), int(c["ref_pos"]),
+                             int(c["query_pos"]), ref_id=int(c["ref_id"]), query_id=int(c["query_id"]), ref_name="r", query_name="q")
+        if line != orc.format_line(r, "r", "q"):
+            raise SystemExit("bench.py: PARITY FAILURE between the HIP engine and the reference's own GACT on candidate %d:\n %s %s"
+                             % (k, line, orc.format_line(r, "r", "q")))
+        cells += int(r["cells"]); n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(cells / dt / 1e9, 5), "unit": "GCUPS", "cores": 1, "kind": "reference",
+            "sample": "%d forward-strand candidates of this workload (%d cells, %.1f s) through the reference's own GACT / AlignWithBT "
+                      "(align.cpp, gact.cpp compiled unchanged; align.cpp:85 allocates 16.8 MB per tile); lines equal to the HIP records"
+                      % (n, cells, dt)}
+
+
+def side_config(name, args):
+    """One of the other single-GPU configurations (BASELINE.json configs[2], configs[4]): built exactly like the
+    headline workload, 3 timed steps after 1 warm-up, parity gate against the oracle on a sample."""
+    import numpy as np
+    import oracle_py
+    from gact_amd import engine, workload
+    blk = workload.make_block(name, candidates=args.candidates)
+    cat, offs = blk.rs.concat()
+    rcat, roffs = blk.rs.concat(rc=True)
+    eng = engine.Engine(n_slots=1)
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+    nf, nr = len(blk.cf), len(blk.cr)
+    eng.candidates_upload(np.concatenate([blk.cf, blk.cr]))
+    rec = np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE)
+    eng.register_output(rec)
+    steps, stats = 3, []
+    for k in range(1 + steps):
+        if k == 1:
+            eng.sync(0)
+            t0 = time.perf_counter()
+        eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True)
+        eng.candidates_fetch(nf + nr, out=rec)
+        if k:
+            stats.append(eng.last_run_stats())
+    dt = (time.perf_counter() - t0) / steps
+    cells = int(rec["cells"].sum())
+    # parity gate: a strided sample of both strands through the oracle, ~4 s of host time
+    orc = oracle_py.Oracle()
+    threads = host_cores()
+    fields = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
+    target = 1.0e10                                  # cells through the oracle
+    stride = max(1, int(cells / target))
+    checked = 0
+    for comp, sl, qcat, qoffs in ((False, slice(0, nf), cat, offs), (True, slice(nf, nf + nr), rcat, roffs)):
+        c, got = np.concatenate([blk.cf, blk.cr])[sl][::stride], rec[sl][::stride]
+        want, _ = orc.gact_many(cat, offs, qcat, qoffs, c, complement=comp, same_file=True, n_threads=threads)
+        if not all(np.array_equal(got[f], want[f]) for f in fields):
+            raise SystemExit("bench.py: PARITY FAILURE between the HIP engine and the oracle on workload %s" % name)
+        checked += len(c)
+    st = stats[-1]
+    eng.close()
+    return {"workload": name + "_self_overlap", "value": round(cells / dt / 1e9, 2), "unit": "GCUPS", "steps": steps, "warmup": 1,
+            "ms_per_step": round(dt * 1e3, 3), "candidates": int(nf + nr), "tiles": int(rec["n_tiles"].sum()), "cells_per_step": cells,
+            "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else ""),
+            "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
+            "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
+            "parity": {"checked_candidates": int(checked), "bit_exact": True}}
 
 
 if __name__ == "__main__":

@@ -142,6 +142,8 @@ __device__ __forceinline__ bool chain_first_tile(ChainState &s, const KParams &k
 // reading of the clock is a scalar memory round trip of its own (~1 k clocks): the sum is an upper bound that is
 // mostly the measurement, and it lengthens the walk it is taken in -- off unless asked for.
 __device__ unsigned long long g_refill_clocks;
+// look-ahead walker: walks, team iterations, team refills, loop trips of the wave (= its slowest team), columns
+__device__ unsigned long long g_walk_counts[5];
 #endif
 
 // running rescoring state of one candidate while its states stream by
@@ -180,7 +182,7 @@ struct ScoreWalk {
 //     score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE step g; after a diagonal
 //     move v is H of the new cell, and ZERO means v == 0 (align.cpp:166-168: M <= 0, I <= 0, D <= 0, i.e. H == 0).
 // Position arithmetic, region cache and arguments as in walk_chain below.
-template <int CW, int QN, int LANES>
+template <int CW, int QN, int ROW>
 __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                                int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                                const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
@@ -208,7 +210,7 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
 #ifdef GACT_STAMPS_REFILL
         struct Acc { unsigned long long &sum, t0; __device__ ~Acc() { sum += __builtin_amdgcn_s_memtime() - t0; } } acc_{rf_clk, __builtin_amdgcn_s_memtime()};
 #endif
-        tb_refill_oct<CW, QN, LANES>(ws_all, ws_off, scratch, l, c, k, rg);
+        tb_refill_oct<CW, QN, ROW>(ws_all, ws_off, scratch, l, c, k, rg);
         off0 = 4 * (-8 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
     };
@@ -284,31 +286,37 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
 //   * a cell that holds INSERT / DELETE at the head is one gap step, as in walk_chain_lin.
 // Semantics are walk_chain_lin's, step for step (same cells, same order, same stop tests); only how many steps one
 // trip through the loop takes differs.
-// Region cache: rows i-16..i x columns j-16..j of the anchor cell = up to three lanes x three flush blocks x all the
-// lane's column octets = 18 uint4, loaded by the team together (two or three 16-byte loads per lane, one memory round
-// trip) whenever the head has moved more than eight rows or columns from the anchor, so eight cells of look-ahead are
-// always inside.
-constexpr int kLaTeam = 8, kLaSpan = 16, kLaRefill = 8;
-template <int CW, int QN> struct LaRegion {
-    static constexpr int NL = CW >= kLaSpan ? 2 : 3;       // lanes 17 adjacent columns can touch
-    static constexpr int NB = 3;                           // flush blocks 17 adjacent stored steps can touch
+// Region cache: rows i-SPAN..i x columns j-SPAN..j of the anchor cell (SPAN 32 in the main launch: up to four or five
+// lanes x five flush blocks x all the lane's column octets = 40-50 uint4; SPAN 16 = 18 uint4 in the seed launch),
+// loaded by the team together (a few 16-byte loads per lane, ONE memory round trip) whenever the head has moved more
+// than SPAN - 7 rows or columns from the anchor, so eight cells of look-ahead are always inside.  The round trip is
+// what a walk is made of now (the words of a 200 x 200 window are 14 KB per tile, 43 MB per XCD in flight: they come
+// back from beyond the L2, ~3,500 clocks each time), and every team of the wave takes its refill at the same trip.
+constexpr int kLaTeam = 8;
+#ifndef GACT_WALK_SYNC_REFILL
+#define GACT_WALK_SYNC_REFILL 1
+#endif
+// SPAN: the cached region is rows i-SPAN..i x columns j-SPAN..j of the anchor cell
+template <int CW, int QN, int SPAN> struct LaRegion {
+    static constexpr int NL = (SPAN + CW - 1) / CW + 1;    // lanes SPAN + 1 adjacent columns can touch
+    static constexpr int NB = SPAN / 8 + 1;                // flush blocks SPAN + 1 adjacent stored steps can touch
     static constexpr int kUint4 = NL * NB * QN;
-    static_assert(2 * CW >= kLaSpan, "three lanes cover the region");
-    static_assert(kUint4 <= 3 * kLaTeam, "three loads per lane fill the region");
-    static_assert(kUint4 * 4 <= kTbScratchWords, "LDS scratch of a walker");
-    static_assert(kLaRefill + kLaTeam - 1 <= kLaSpan, "eight cells of look-ahead stay inside the region between refills");
+    static constexpr int kLoads = (kUint4 + kLaTeam - 1) / kLaTeam;    // 16-byte loads per lane and refill
+    static constexpr int kWords = kUint4 * 4;              // dwords of LDS scratch per walker
+    static constexpr int kRefill = SPAN - (kLaTeam - 1);   // the head may be this far from the anchor when a trip begins
+    static_assert(SPAN % 8 == 0 && SPAN >= 16, "whole flush blocks");
 };
 
-template <int CW, int QN, int LANES>
+template <int CW, int QN, int ROW, int SPAN>
 __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const bool active, int R, int Q, int l0, int c0, int k0,
                                                     int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                                     const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
                                                     int &nst, int v0, const uint32_t *ws, const uint32_t *ws_all)
 {
-    using RG = LaRegion<CW, QN>;
+    using RG = LaRegion<CW, QN, SPAN>;
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     constexpr uint32_t kM = 3u, kI = 2u;                        // align.h:23 numbering, as the pass tags them
-    constexpr int kOct = 16 * LANES, kBlk = 16 * QN * LANES;    // byte strides of a column octet, of a flush block
+    constexpr int kOct = 16 * ROW, kBlk = 16 * QN * ROW;        // byte strides of a column octet, of a flush block
     constexpr int kRow = 16 * QN;                               // bytes of one cached (lane, flush block)
     const int lane = threadIdx.x & 63, m = lane & (kLaTeam - 1);
     const uint32_t team_shift = (uint32_t)lane & 56u;
@@ -322,41 +330,40 @@ __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const boo
     LdsByte *cache = (LdsByte *)scratch;
     const uint32_t ws_off = (uint32_t)((const char *)ws - (const char *)ws_all);   // the workspace is under 4 GB (engine)
 
-    // this lane's loads of a refill: uint4 n = m, m + 8, m + 16 of the region, n = (slot * NB + block) * QN + octet
-    // (slot s = lane l_anchor - s)
-    int ld_n[3], ld_slot[3], ld_stat[3];
+    // this lane's loads of a refill: uint4 n = m, m + 8, ... of the region, n = (slot * NB + block) * QN + octet
+    // (slot s = lane l_anchor - s; its first cached block is f(s) = max(((k_anchor - s) >> 3) - (NB - 1), 0))
+    int ld_n[RG::kLoads], ld_slot[RG::kLoads], ld_stat[RG::kLoads];
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < RG::kLoads; r++) {
         const int n = imin(m + kLaTeam * r, RG::kUint4 - 1);
         const int slot = n / (RG::NB * QN), rem = n - slot * (RG::NB * QN), blk = rem / QN, oct = rem - blk * QN;
         ld_n[r] = n; ld_slot[r] = slot; ld_stat[r] = blk * kBlk + oct * kOct;
     }
-    int la = 0, b0 = 0, b1 = 0, b2 = 0;                         // anchor lane; cache offsets of the three slots
+    int la = 0, ka = 0;                                         // anchor: lane and stored step (in that lane)
+    auto first_block = [](int k_lane) { return imax((k_lane >> 3) - (RG::NB - 1), 0); };
     auto refill = [&](int l_a, int k_a) {
-        const int f0 = imax((k_a >> 3) - 2, 0), f1 = imax(((k_a - 1) >> 3) - 2, 0), f2 = imax(((k_a - 2) >> 3) - 2, 0);
-        uint32_t a[3];
+        u32x4 q[RG::kLoads];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+        for (int r = 0; r < RG::kLoads; r++) {
             const int sl = ld_slot[r];
-            const int fb = sl == 0 ? f0 : sl == 1 ? f1 : f2;
-            a[r] = ws_off + (uint32_t)(fb * kBlk + ld_stat[r] + imax(l_a - sl, 0) * 16);
+            const uint32_t a = ws_off + (uint32_t)(first_block(k_a - sl) * kBlk + ld_stat[r] + imax(l_a - sl, 0) * 16);
+            // (s_nop: the base may have just been written by a VALU instruction -- a v_readlane_b32 out of a spill lane --
+            // and a memory instruction must not read such an SGPR for five wait states)
+            asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 sc1" : "=&v"(q[r]) : "v"(a), "s"(ws_all) : "memory");
         }
-        u32x4 q0, q1, q2;
-        // (s_nop: the base may have just been written by a VALU instruction -- a v_readlane_b32 out of a spill lane --
-        // and a memory instruction must not read such an SGPR for five wait states)
-        asm volatile("s_nop 4\n\t"
-                     "global_load_dwordx4 %0, %3, %6 sc1\n\t"
-                     "global_load_dwordx4 %1, %4, %6 sc1\n\t"
-                     "global_load_dwordx4 %2, %5, %6 sc1\n\t"
-                     "s_waitcnt vmcnt(0)"
-                     : "=&v"(q0), "=&v"(q1), "=&v"(q2)
-                     : "v"(a[0]), "v"(a[1]), "v"(a[2]), "s"(ws_all)
-                     : "memory");
+        if constexpr (RG::kLoads == 3)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) :: "memory");
+        else if constexpr (RG::kLoads == 5)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]) :: "memory");
+        else {
+            static_assert(RG::kLoads == 7, "refill sizes in use");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]) :: "memory");
+        }
         u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
-        dst[ld_n[0]] = q0; dst[ld_n[1]] = q1; dst[ld_n[2]] = q2;
+#pragma unroll
+        for (int r = 0; r < RG::kLoads; r++) dst[ld_n[r]] = q[r];
         wave_sync();
-        la = l_a;
-        b0 = kRow * (0 * RG::NB - f0); b1 = kRow * (1 * RG::NB - f1); b2 = kRow * (2 * RG::NB - f2);
+        la = l_a; ka = k_a;
     };
     // the three column scores in VGPRs (see walk_chain_lin)
     int v = v0, v_gap, v_mism, v_dsub;
@@ -366,10 +373,20 @@ __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const boo
     int nis = 0, njs = 0;                                       // minus the ref / query steps taken (the head cell)
     int di = 0, dj = 0;                                         // rows / columns the head has moved from the anchor
     bool go = active && R >= 1 && Q >= 1 && early > 0 && v0 != 0;
+#ifdef GACT_STAMPS
+    int n_it = 0, n_rf = 0;
+    const bool walked = go;
+#endif
+#ifdef GACT_STAMPS_REFILL
+    unsigned long long rf_clk = 0;
+#endif
     if (go) refill(l0, k0);
     const uint32_t below = (2u << m) - 1u;                      // cells 0..m of the diagonal
     while (go) {
-        // ---- this lane's cell: m steps up the diagonal from the head.  The head is at most kLaRefill rows and columns
+#ifdef GACT_STAMPS
+        n_it++;
+#endif
+        // ---- this lane's cell: m steps up the diagonal from the head.  The head is at most RG::kRefill rows and columns
         //      from the anchor here, so the cell is inside the cached region
         const int ci = nis - m, cj = njs - m;
         // (a cell beyond the end of the walk may lie outside the tile: keep its addresses inside the stored window)
@@ -378,7 +395,7 @@ __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const boo
         const int c = p + __mul24(l, -CW);
         const int k = imax(kA + l + ci, 0);
         const int sl = la - l;
-        const uint32_t at = (uint32_t)((sl == 0 ? b0 : sl == 1 ? b1 : b2) + __mul24(k >> 3, kRow) + ((c >> 1) << 2));
+        const uint32_t at = (uint32_t)(__mul24(__mul24(sl, RG::NB) - first_block(ka - sl) + (k >> 3), kRow) + ((c >> 1) << 2));
         const uint32_t w = *(LdsWord *)(cache + at);
         const uint32_t rb = ra[ci * rstride], qb = qa[cj];
         const uint32_t op = __builtin_amdgcn_ubfe(w, (((uint32_t)c & 1u) << 4) + 14u - (((uint32_t)k & 7u) << 1), 2u);
@@ -401,13 +418,44 @@ __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const boo
         v -= head_m ? dv_run : v_gap;
         nis -= n_i; njs -= n_j; di += n_i; dj += n_j;
         go = head_m ? !halted : !((nis <= nlim_i) | (njs <= nlim_j));
-        if (go && imax(di, dj) > kLaRefill) {
+#if GACT_WALK_SYNC_REFILL
+        // every team of the wave re-anchors when one has to: a refill is a memory round trip that the whole wave waits
+        // for, so the teams take theirs together
+        if (__any(go && imax(di, dj) > RG::kRefill) && go) {
+#else
+        if (go && imax(di, dj) > RG::kRefill) {
+#endif
             const int ph = imax(p0 + njs, 0);
             const int lh = (int)(__umul24((uint32_t)ph, kMagic) >> 16);
+#ifdef GACT_STAMPS_REFILL
+            const unsigned long long rf_t0 = __builtin_amdgcn_s_memtime();
+#endif
             refill(lh, imax(kA + lh + nis, 0));
+#ifdef GACT_STAMPS_REFILL
+            rf_clk += __builtin_amdgcn_s_memtime() - rf_t0;
+#endif
             di = 0; dj = 0;
+#ifdef GACT_STAMPS
+            n_rf++;
+#endif
         }
     }
+#ifdef GACT_STAMPS
+    {
+        int trips = n_it;
+        for (int mm = 1; mm < 64; mm <<= 1) trips = imax(trips, __shfl_xor(trips, mm, 64));
+        if (walked && m == 0) {
+            atomicAdd(&g_walk_counts[0], 1ull); atomicAdd(&g_walk_counts[1], (unsigned long long)n_it);
+            atomicAdd(&g_walk_counts[2], (unsigned long long)n_rf); atomicAdd(&g_walk_counts[4], (unsigned long long)(-nis - njs));
+        }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_walk_counts[3], (unsigned long long)trips);
+#ifdef GACT_STAMPS_REFILL
+        // (the longest-waiting lane of the wave: refills are taken by all teams together)
+        for (int mm = 1; mm < 64; mm <<= 1) { const unsigned long long o = __shfl_xor(rf_clk, mm, 64); rf_clk = o > rf_clk ? o : rf_clk; }
+        if ((threadIdx.x & 63) == 0) atomicAdd(&g_refill_clocks, rf_clk);
+#endif
+    }
+#endif
     ref_steps = -nis; query_steps = -njs;
     nst = -nis - njs;                                            // only "were there any columns" is asked (chain_advance)
     wk.score += v0 - v;                                          // what the columns of this tile scored
@@ -437,14 +485,14 @@ __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const boo
 // byte stride.  (l0, c0, k0) = lane, column-in-lane and stored step of the start cell
 // (R, Q) in the pass's layout; CW columns per lane, QN column quads stored per lane.
 //
-template <int CW, int FMT, int QN = CW / 4, int LANES = kGroup>
+template <int CW, int FMT, int QN = CW / 4, int ROW = kGroup>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
                                            int &query_steps, int &nst, int v0 = 0, const uint32_t *ws_all = nullptr)
 {
     if constexpr (FMT == 3) {
-        walk_chain_lin<CW, QN, LANES>(ws, scratch, R, Q, l0, c0, k0, early, rrow, rstride, qrow, kp, wk, ref_steps,
+        walk_chain_lin<CW, QN, ROW>(ws, scratch, R, Q, l0, c0, k0, early, rrow, rstride, qrow, kp, wk, ref_steps,
                                       query_steps, nst, v0, ws_all);
         return;
     }
@@ -461,7 +509,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
 
     auto refill = [&](int l, int c, int k) {
-        tb_refill_at<CW, QN, LANES>(ws, scratch, l, c, k, rg);
+        tb_refill_at<CW, QN, ROW>(ws, scratch, l, c, k, rg);
         off0 = 4 * (-12 * rg.fbase[0] - 4 * rg.qbase0);
         off1 = 4 * (24 - 12 * rg.fbase[1] - 4 * (QN - 3));
     };

@@ -433,7 +433,7 @@ __device__ __forceinline__ void traceback(const uint32_t *ws, int i, int j, int 
 // 12 uint4) from the HBM workspace into its own LDS scratch -- all 12 loads in
 // flight at once, one latency per 8 steps -- and the steps in between read LDS.
 constexpr int kTbSpan = 8;
-constexpr int kTbScratchWords = 18 * 4;      // dwords of LDS per walker (12 uint4 of tb_refill_at, 18 of the look-ahead walker's region)
+constexpr int kTbScratchWords = 18 * 4;      // dwords of LDS per walker (12 uint4 of tb_refill_at, 18 of the seed launch's look-ahead region)
 
 template <int CW> struct TbRegion {
     int l0;              // lane of the anchor column
@@ -441,17 +441,23 @@ template <int CW> struct TbRegion {
     int qbase0;          // first cached column quad of lane l0 (lane l0-1 always caches its last three)
 };
 
-// Workspace layout of one flush block (8 stored steps of a tile): [quad 0..QN-1][lane] uint4, a quad = the pointer
-// words of four adjacent columns (eight in the linear-gap pass's format, below).
-template <int QN, int LANES>
+// Workspace layout of one flush block (8 stored steps of a tile): [quad 0..QN-1][ROW uint4], a quad = the pointer
+// words of four adjacent columns (eight in the linear-gap pass's format, below), ROW = how many uint4 lie between two
+// quads of one lane.  The int32 kernels keep a tile's words to themselves (ROW = its 16 lanes).  The packed kernels
+// interleave the eight tiles of a WAVE: a row is [tile A | tile B][the wave's 64 lanes] = kWsRow uint4, so that one
+// store instruction of the pass writes ONE KB of adjacent bytes.  With a row per tile (four 256-byte pieces 55 KB
+// apart per store instruction) the four stores of a flush cost a wave ~940 clocks, with adjacent bytes ~100
+// (tools/store_probe.hip, profiles/r03/store_probe.json) -- 0.3 % of the pass's instructions were 17 % of its time.
+constexpr int kWsRow = 2 * 64;
+template <int QN, int ROW>
 __device__ __forceinline__ const u32x4 *ws_quad_addr(const u32x4 *base, int blk, int q, int lane)
 {
-    return base + (blk * QN + q) * LANES + lane;
+    return base + (blk * QN + q) * ROW + lane;
 }
 
 // anchor cell given as (lane l0, column-in-lane c0, stored step k0 = i + l0 - tB)
 // CW = columns per lane, QN = 16-byte column quads stored per lane and flush block
-template <int CW, int QN = CW / 4, int LANES = kGroup>
+template <int CW, int QN = CW / 4, int ROW = kGroup>
 __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scratch, int l0, int c0, int k0,
                                              TbRegion<CW> &rg)
 {
@@ -470,7 +476,7 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
         for (int lev = 0; lev < 2; lev++)
 #pragma unroll
             for (int qq = 0; qq < 3; qq++)
-                addr[(sl * 2 + lev) * 3 + qq] = ws_quad_addr<QN, LANES>(base, fb + lev, imin(qb + qq, QN - 1), lane);
+                addr[(sl * 2 + lev) * 3 + qq] = ws_quad_addr<QN, ROW>(base, fb + lev, imin(qb + qq, QN - 1), lane);
     }
     u32x4 r[12];
 #pragma unroll
@@ -497,35 +503,36 @@ __device__ __forceinline__ void tb_refill_at(const uint32_t *ws, uint32_t *scrat
 // Written for few instructions (a refill runs at the walker's pace, one instruction per 8-10 clocks): the workspace
 // is addressed as ws_all + a 32-bit byte offset (ws_off = the tile's own), a lane's four loads are one offset plus
 // immediates (block and octet strides fit the instruction's offset field).
-template <int CW, int QN, int LANES>
+template <int CW, int QN, int ROW>
 __device__ __forceinline__ void tb_refill_oct(const uint32_t *ws_all, uint32_t ws_off, uint32_t *scratch, int l0, int c0,
                                               int k0, TbRegion<CW> &rg)
 {
     static_assert(QN >= 2 && CW > 8 && ((CW - 9) >> 3) + 1 <= QN - 1, "two column octets per lane at least; octet qbase0 + 1 exists");
-    constexpr int kOct = 16 * LANES, kBlk = 16 * QN * LANES;       // byte strides of a column octet, of a flush block
-    static_assert(kBlk + kOct < 4096, "immediate offsets");
+    constexpr int kOct = 16 * ROW, kBlk = 16 * QN * ROW;           // byte strides of a column octet, of a flush block
     rg.l0 = l0;
     rg.qbase0 = imax(c0 - kTbSpan, 0) >> 3;                        // nine adjacent columns lie in octets qbase0, qbase0 + 1
     rg.fbase[0] = imax((k0 >> 3) - 1, 0);
     rg.fbase[1] = imax(((k0 - 1) >> 3) - 1, 0);
     const uint32_t a0 = ws_off + (uint32_t)(rg.fbase[0] * kBlk + rg.qbase0 * kOct + l0 * 16);
     const uint32_t a1 = ws_off + (uint32_t)(rg.fbase[1] * kBlk + (QN - 2) * kOct + imax(l0 - 1, 0) * 16);
+    const uint32_t a0o = a0 + kOct, a0b = a0 + kBlk, a0bo = a0 + kBlk + kOct;
+    const uint32_t a1o = a1 + kOct, a1b = a1 + kBlk, a1bo = a1 + kBlk + kOct;
     u32x4 r[8];
     // (s_nop: the base may have just been written by a VALU instruction -- a v_readlane_b32 out of a spill lane --
     // and a memory instruction must not read such an SGPR for five wait states; the compiler's hazard recogniser
     // does not look inside this statement)
     asm volatile("s_nop 4\n\t"
-                 "global_load_dwordx4 %0, %8, %10 sc1\n\t"
-                 "global_load_dwordx4 %1, %8, %10 offset:%11 sc1\n\t"
-                 "global_load_dwordx4 %2, %8, %10 offset:%12 sc1\n\t"
-                 "global_load_dwordx4 %3, %8, %10 offset:%13 sc1\n\t"
-                 "global_load_dwordx4 %4, %9, %10 sc1\n\t"
-                 "global_load_dwordx4 %5, %9, %10 offset:%11 sc1\n\t"
-                 "global_load_dwordx4 %6, %9, %10 offset:%12 sc1\n\t"
-                 "global_load_dwordx4 %7, %9, %10 offset:%13 sc1\n\t"
+                 "global_load_dwordx4 %0, %8, %16 sc1\n\t"
+                 "global_load_dwordx4 %1, %9, %16 sc1\n\t"
+                 "global_load_dwordx4 %2, %10, %16 sc1\n\t"
+                 "global_load_dwordx4 %3, %11, %16 sc1\n\t"
+                 "global_load_dwordx4 %4, %12, %16 sc1\n\t"
+                 "global_load_dwordx4 %5, %13, %16 sc1\n\t"
+                 "global_load_dwordx4 %6, %14, %16 sc1\n\t"
+                 "global_load_dwordx4 %7, %15, %16 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-                 : "v"(a0), "v"(a1), "s"(ws_all), "i"(kOct), "i"(kBlk), "i"(kBlk + kOct)
+                 : "v"(a0), "v"(a0o), "v"(a0b), "v"(a0bo), "v"(a1), "v"(a1o), "v"(a1b), "v"(a1bo), "s"(ws_all)
                  : "memory");
     u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
 #pragma unroll

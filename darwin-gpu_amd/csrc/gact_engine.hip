@@ -184,6 +184,7 @@ struct gact_hip_engine {
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
     int seed_lin_grid_blocks = 0;       // ... of its linear-gap form (3)
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
+    int wide_lin_grid_blocks = 0;       // ... of the linear-gap wide launch
     gact::P16Consts kc;
     hipDeviceProp_t prop;
     int grid_blocks = 0;        // persistent grid
@@ -383,7 +384,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // at one instruction per ~11 cycles with one neighbour on its SIMD, ~15 with two (8 alone, but then half the
         // VALU idles): ONT-shape workload 150 ms -> 116 ms; one wave per SIMD: 132 ms
         const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : 2;
-        const int wide_cap = std::min(e->grid_blocks, per_cu * e->prop.multiProcessorCount);
+        const int wide_cap = std::min(sl.lin ? e->wide_lin_grid_blocks : e->grid_blocks, per_cu * e->prop.multiProcessorCount);
         const int wide_blocks = std::max(1, std::min((n + 15) / 16, wide_cap));             // 4 tiles per wave
         const int lin_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->lin_grid_blocks));
         hipLaunchKernelGGL(km, dim3(sl.wide ? wide_blocks : (sl.lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, sl.stream, kp,
@@ -402,7 +403,7 @@ template <int C> int occupancy_blocks(int *out)
     int m = std::min(a, b);
     for (int v = 0; v < 14; v++) {
         int c = m;
-        if (v == 12) continue;          // the linear-gap split launch has its own grid (lin_occupancy_blocks)
+        if (v == 12 || v == 13) continue;   // the linear-gap launches have their own grids (lin_occupancy_blocks, wide_lin_grid_blocks)
         auto k = v == 13 ? gact::extend_p16_kernel<gact::WideLayoutLin, false>
                : v == 0 ? gact::extend_p16_kernel<gact::UniformLayout<C>, true>
                : v == 1 ? gact::extend_p16_kernel<gact::UniformLayout<C>, false>
@@ -589,12 +590,17 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         int lb = 0;
         if ((rc = lin_occupancy_blocks(&lb))) { delete e; return rc; }
         e->lin_grid_blocks = std::max(e->grid_blocks, lb * e->prop.multiProcessorCount);
-        if ((ws_words_for(e->lin_grid_blocks) + 64) * sizeof(uint32_t) >= (1ull << 32)) {
+        int wb = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wb, gact::extend_p16_kernel<gact::WideLayoutLin, false>,
+                                                             gact::kBlockThreads, 0));
+        e->wide_lin_grid_blocks = std::max(e->grid_blocks, wb * e->prop.multiProcessorCount);
+        if ((ws_words_for(std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)) + 64) * sizeof(uint32_t) >= (1ull << 32)) {
             e->lin = false;
             e->lin_grid_blocks = e->grid_blocks;
         }
     }
-    e->ws_words_total = ws_words_for(std::max(e->grid_blocks, e->lin_grid_blocks));
+    if (!e->lin) e->wide_lin_grid_blocks = e->grid_blocks;
+    e->ws_words_total = ws_words_for(std::max(e->grid_blocks, std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
     e->slots.resize(p->n_slots);
     for (auto &sl : e->slots) {
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1042,6 +1048,16 @@ int gact_hip_debug_timeline(gact_hip_engine *e, unsigned long long *out, int n_w
     return 0;
 }
 
+// diagnostic build: shader clocks each of those waves lived (with the timeline's 100 MHz stamps: the clock the chip held)
+int gact_hip_debug_wave_cycles(gact_hip_engine *e, unsigned long long *out, int n_waves)
+{
+    int rc = set_device(e);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(gact::g_wave_cycles), (size_t)std::min(n_waves, 4096) * sizeof(unsigned long long)));
+    return 0;
+}
+
 // diagnostic build: read and clear the per-phase clock totals of extend_p16_kernel
 int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
 {
@@ -1060,6 +1076,20 @@ int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
     HIP_TRY(hipMemcpyFromSymbol(&rf, HIP_SYMBOL(gact::g_refill_clocks), sizeof rf));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_refill_clocks), &zero, sizeof zero));
     if (y[6] && rf) printf("  walker region refills (upper bound, -DGACT_STAMPS_REFILL): %llu clocks/iter\n", rf / y[6]);
+#ifdef GACT_STAMPS_FLUSH
+    {
+        unsigned long long fc[3], fz[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyFromSymbol(fc, HIP_SYMBOL(gact::g_flush_clocks), sizeof fc));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_flush_clocks), fz, sizeof fz));
+        if (fc[1]) printf("  pointer flushes of the split pass: %llu, %.0f clocks each (clock readings included), of which from the first store on: %.0f\n",
+                          fc[1], (double)fc[0] / fc[1], (double)fc[2] / fc[1]);
+    }
+#endif
+    unsigned long long wc[5], wz[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyFromSymbol(wc, HIP_SYMBOL(gact::g_walk_counts), sizeof wc));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_walk_counts), wz, sizeof wz));
+    if (wc[0]) printf("  look-ahead walker: %llu walks, %.1f columns, %.1f team iterations and %.1f refills per walk; %.1f loop trips per wave pass\n",
+                      wc[0], (double)wc[4] / wc[0], (double)wc[1] / wc[0], (double)wc[2] / wc[0], y[6] ? (double)wc[3] / y[6] : 0.0);
     return 0;
 }
 #endif

@@ -39,8 +39,19 @@
 
 namespace gact {
 
+// 5. One instruction for two of the three maxima.  Every value of the pass is a positive int16 below 0x7C00, and positive
+//    IEEE half-precision numbers order exactly like their bit patterns: max(M', Z, H'_up) -- off the serial column chain --
+//    is ONE v_pk_maximum3_f16 (gfx950) where the integer instruction set needs two v_pk_max_i16.  The maximum returns one
+//    of its operands bit for bit (no NaN below 0x7C00; lin_base keeps every value at or above 0x0400, a normal number,
+//    whatever the denormal mode).  5 instructions per cell pair for the scores, 9 where pointers are made; the slow
+//    instruction class (3.2 cycles at three waves) goes from 4 to 3 / from 5 to 4 of them.
+#ifndef GACT_LIN_MAX3
+#define GACT_LIN_MAX3 1
+#endif
+constexpr int kLinFloor = GACT_LIN_MAX3 ? 1024 : 0;
 // zero level of lane 0 before step 1: above 31 lanes' worth of drift plus one gap, so nothing ever goes below |g|
-__host__ __device__ constexpr int lin_base(int g) { return 40 * (-g) + 8; }
+// (below kLinFloor + |g|)
+__host__ __device__ constexpr int lin_base(int g) { return kLinFloor + 40 * (-g) + 8; }
 // a wave-uniform constant the compiler must keep in a VGPR (an SGPR operand would put the instruction in the slow class)
 __device__ __forceinline__ uint32_t vconst(uint32_t s)
 {
@@ -55,13 +66,20 @@ __host__ inline bool p16_lin_ok(int tile, int match, int mismatch, int open, int
     const long long steps = (long long)tile + 4 * kGroup + 64 + 48;        // drift of the longest pass + lin_base
     return open == ext && mismatch == ext && ext <= 0 && match >= 0 &&
            p16_tagged_ok(tile, match, mismatch, open, ext) &&
-           4 * ((long long)match * (tile + 2) + (long long)(-ext) * steps) + 3 <= 30000 && match - ext <= 63;
+           4 * ((long long)match * (tile + 2) + (long long)(-ext) * steps + kLinFloor) + 3 <= 30000 && match - ext <= 63;
 }
 
 __device__ __forceinline__ uint32_t pk_mad4v(uint32_t a, uint32_t v_c)     // a * 4 + c (wrapping halves), c in a VGPR
 {
     uint32_t r;
     asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(v_c));
+    return r;
+}
+// max of three positive int16 pairs as half-precision numbers (see 5. above)
+__device__ __forceinline__ uint32_t pk_max3f(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ uint32_t pk_ashr2(uint32_t a)
@@ -78,10 +96,19 @@ template <int CW> struct LinWords {
     static constexpr int kWords = (CW + 1) / 2;          // dwords per lane, tile and flush
     static constexpr int kUint4 = (kWords + 3) / 4;
 };
+#ifdef GACT_STAMPS_FLUSH
+__device__ unsigned long long g_flush_clocks[3];     // diagnostic: shader clocks inside the split pass's flushes, their number, clocks of the stores alone
+#define g_flush_mid fl_mid_
+#endif
 // acc[c]: the codes of column c, tile A in the low half-word, tile B in the high one
 template <int NW, int LANES, class Fix>
-__device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *qA, uint4 *qB, Fix fix, const bool store = true)
+__device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *qA, uint4 *qB, Fix fix, const bool store = true,
+                                          unsigned long long *mid = nullptr)
 {
+#ifdef GACT_STAMPS_FLUSH
+    unsigned long long fl_mid_ = 0;
+    struct MidOut { unsigned long long *dst, &v; __device__ ~MidOut() { if (dst) *dst = v; } } mid_out_{mid, fl_mid_};
+#endif
     constexpr int QD = (NW + 3) / 4;
     uint32_t wa[QD * 4], wb[QD * 4];
 #pragma unroll
@@ -90,11 +117,65 @@ __device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *
         wb[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x07060302u)) : 0u;
     }
     if (!store) return;          // a lane whose columns no walk can reach (uniform layout, non-first tiles)
+#ifdef GACT_STAMPS_FLUSH
+    {
+        uint32_t x = 0;
+#pragma unroll
+        for (int n = 0; n < QD * 4; n++) x ^= wa[n] ^ wb[n];
+        asm volatile("" :: "v"(x));                       // the re-paired words exist before the clock is read
+        g_flush_mid = __builtin_amdgcn_s_memtime();
+    }
+#endif
+#if GACT_EXP_STORE_CONST
+    // timing experiment (wrong results): the same stores, but of registers nobody writes again -- are the stores dear
+    // because the step that follows overwrites their data registers while they are still pending?
+    {
+        uint32_t x = 0;
+#pragma unroll
+        for (int n = 0; n < QD * 4; n++) x ^= wa[n] ^ wb[n];
+        asm volatile("" :: "v"(x));
+        const uint32_t k0 = (uint32_t)(uintptr_t)qA, k1 = (uint32_t)(uintptr_t)qB;
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            qA[q * kWsRow] = make_uint4(k0, k1, k0, k1);
+            qB[q * kWsRow] = make_uint4(k1, k0, k1, k0);
+        }
+    }
+#elif GACT_PTR_BUFFER_STORE
+    // the same four stores as buffer_store_dwordx4 through a raw buffer descriptor over the wave's workspace
+    // (GACT_PTR_BUFFER_STORE == 2, timing experiment: a descriptor of zero records -- the range check drops the stores)
+    {
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        const uint64_t base = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)qA) |
+                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)qA >> 32)) << 32);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, GACT_PTR_BUFFER_STORE == 2 ? 0 : 0x7fffff00, 0x00020000);
+        const int oa = (int)((uintptr_t)qA - base), ob = (int)((uintptr_t)qB - base);
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            const u32x4_t da = {wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]};
+            const u32x4_t db = {wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(da, rs, oa + q * kWsRow * 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(db, rs, ob + q * kWsRow * 16, 0, 0);
+        }
+    }
+#elif GACT_EXP_STORE_ONE == 1
+    // timing experiment (wrong results): ONE of the stores of a flush
+    {
+        uint32_t x = 0;
+#pragma unroll
+        for (int n = 4; n < QD * 4; n++) x ^= wa[n];
+#pragma unroll
+        for (int n = 0; n < QD * 4; n++) x ^= wb[n];
+        asm volatile("" :: "v"(x));
+        qA[0] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+    }
+#else
 #pragma unroll
     for (int q = 0; q < QD; q++) {
-        qA[q * LANES] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
-        qB[q * LANES] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+        qA[q * kWsRow] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
+        qB[q * kWsRow] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -151,11 +232,17 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
             for (int c = C1; c < CT; c++) P[c] = G[c] - onev;                    // H_up tagged 2
         }
         GACT_SB();
+        if (GACT_LIN_MAX3) {
 #pragma unroll
-        for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], c < C1 ? Z1 : Zr2);     // :145-147
-        GACT_SB();
+            for (int c = 0; c < CT; c++)                                         // :145-147 and the insertion, :149-154
+                U[c] = pk_max3f(U[c], c < C1 ? Z1 : Zr2, (tag2 && c >= C1) ? P[c] : G[c]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], (tag2 && c >= C1) ? P[c] : G[c]);    // the insertion, :149-154
+            for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], c < C1 ? Z1 : Zr2);     // :145-147
+            GACT_SB();
+#pragma unroll
+            for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], (tag2 && c >= C1) ? P[c] : G[c]);    // the insertion, :149-154
+        }
         GACT_SB();
     };
 
@@ -234,22 +321,40 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     if (tagged) enter_tagged();
     uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
     uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
-    auto flush = [&](auto fix) { lin_flush<NW, kGroup>(acc, qA, qB, fix); };
+    // (GACT_EXP_NO_STORE, timing experiment: the words are made but not stored -- a condition the compiler cannot see through)
+    const bool exp_store = !GACT_EXP_NO_STORE || kc.one == 0x7ffe7ffeu;
+    auto flush = [&](auto fix) { lin_flush<NW, kGroup>(acc, qA, qB, fix, exp_store); };
     // whole blocks of eight steps, each followed by its flush (an `if ((k & 7) == 7)` inside one loop is
     // if-converted by the compiler: the re-pairing v_perm of the flush would then run at every step)
     int k = 0;
+#ifdef GACT_STAMPS_FLUSH
+    unsigned long long fl_clk = 0, fl_n = 0, fl_st = 0;
+#endif
     while (t + 7 <= T_end) {
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
+#ifdef GACT_STAMPS_FLUSH
+        { const unsigned long long f0 = __builtin_amdgcn_s_memtime();
+          unsigned long long fm = 0;
+          lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, exp_store, &fm);
+          const unsigned long long f1 = __builtin_amdgcn_s_memtime();
+          fl_clk += f1 - f0; fl_n++; if (fm) fl_st += f1 - fm; }
+#else
         flush([](uint32_t w) { return w; });
-        qA += QD * kGroup;
-        qB += QD * kGroup;
+#endif
+#if !GACT_EXP_STORE_HOME
+        qA += QD * kWsRow;
+        qB += QD * kWsRow;
+#endif
     }
     for (; t <= T_end; t++, k++) step_tagged(t);
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
         flush([sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); });
     }
+#ifdef GACT_STAMPS_FLUSH
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) { atomicAdd(&g_flush_clocks[0], fl_clk); atomicAdd(&g_flush_clocks[1], fl_n); atomicAdd(&g_flush_clocks[2], fl_st); }
+#endif
     // H of the last column at the row of the last step, drift taken off
     return tagged ? pk_ashr2(pk_sub(H2, Z24)) : pk_sub(H2, Z2);
 }
@@ -273,7 +378,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 {
     constexpr int NW = LinWords<C>::kWords, QD = LinWords<C>::kUint4;
     // col_from: first column (1-based) a walk can reach in either tile: lanes left of it keep their words
-    const bool store = AMAX || gl * C + C >= col_from;
+    const bool store = (AMAX || gl * C + C >= col_from) && (!GACT_EXP_NO_STORE || kc.one == 0x7ffe7ffeu);
     static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
     const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), onev = vconst(kc.one),
@@ -324,11 +429,16 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
             for (int c = 0; c < C; c++) P[c] = G[c] - onev;                                    // H_up tagged 2
         }
         GACT_SB();
+        if (GACT_LIN_MAX3) {
 #pragma unroll
-        for (int c = 0; c < C; c++) U[c] = pk_max(U[c], Zr);                                   // :145-147
-        GACT_SB();
+            for (int c = 0; c < C; c++) U[c] = pk_max3f(U[c], Zr, tag2 ? P[c] : G[c]);         // :145-147 and the insertion, :149-154
+        } else {
 #pragma unroll
-        for (int c = 0; c < C; c++) U[c] = pk_max(U[c], tag2 ? P[c] : G[c]);                   // the insertion, :149-154
+            for (int c = 0; c < C; c++) U[c] = pk_max(U[c], Zr);                               // :145-147
+            GACT_SB();
+#pragma unroll
+            for (int c = 0; c < C; c++) U[c] = pk_max(U[c], tag2 ? P[c] : G[c]);               // the insertion, :149-154
+        }
         GACT_SB();
     };
 
@@ -427,8 +537,8 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
         lin_flush<NW, LANES>(acc, qA, qB, [](uint32_t w) { return w; }, store);
-        qA += QD * LANES;
-        qB += QD * LANES;
+        qA += QD * kWsRow;
+        qB += QD * kWsRow;
         if (AMAX) fold(k - 8);
     }
     for (; t <= T_end; t++, k++) step_tagged(t);
@@ -472,6 +582,14 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 // The wide main launch of linear scorings: UniformLayout<10, 32>'s column map, the pass above, FMT 3 words
 struct WideLayoutLin : UniformLayout<10, 32, true> {
     static constexpr int kWalkFmt = 3, kWalkQuads = LinWords<10>::kUint4;
+#ifndef GACT_WALK_SPAN
+#define GACT_WALK_SPAN 16
+#endif
+    static constexpr int kWalkSpan = GACT_WALK_SPAN;          // region cache of the look-ahead walker (gact_chain.hpp)
+#ifndef GACT_WIDE_LIN_BLOCKS
+#define GACT_WIDE_LIN_BLOCKS 3
+#endif
+    static constexpr int kBlocksPerCu = GACT_WIDE_LIN_BLOCKS;  // launch bounds: waves per SIMD the register budget is cut for
     static constexpr bool kEndAligned = true;
     template <bool RAW>
     __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[10], int T_end,
@@ -491,6 +609,7 @@ struct WideLayoutLin : UniformLayout<10, 32, true> {
 template <int C1, int C2> struct SplitLayoutLin : SplitLayout<C1, C2, true> {
     static constexpr int kBlocksPerCu = GACT_LIN_BLOCKS_PER_CU;
     static constexpr int kWalkFmt = 3, kWalkQuads = LinWords<C2>::kUint4;
+    static constexpr int kWalkSpan = GACT_WALK_SPAN;
     static constexpr bool kEndAligned = true;       // every tile's last row on the wave's last step
     template <bool RAW>
     __device__ static uint32_t pass(const P16Consts &kc, int gl, const uint16_t *ref16, const uint32_t (&qb)[C1 + C2],

@@ -30,6 +30,8 @@ __device__ unsigned long long g_stamps[8];
 __device__ unsigned long long g_stamps2[8];
 // per wave of the main launch: start, first time it found the queues empty, end (s_memrealtime, 100 MHz), iterations
 __device__ unsigned long long g_timeline[4 * 4096];
+// shader clocks (s_memtime) each of those waves lived: with the 100 MHz stamps above, the clock the chip held
+__device__ unsigned long long g_wave_cycles[4096];
 #define GACT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #define GACT_ACC(slot, t0, t1) stamp_acc[slot] += (t1) - (t0)
 #else
@@ -37,9 +39,29 @@ __device__ unsigned long long g_timeline[4 * 4096];
 #define GACT_ACC(slot, t0, t1)
 #endif
 
-// -DGACT_WALK_SINGLE_LANE=1: the linear-gap format walked by one lane per tile (walk_chain_lin), for A/B measurements
-#ifndef GACT_WALK_SINGLE_LANE
-#define GACT_WALK_SINGLE_LANE 0
+// the seed launch's linear-gap walks by teams of eight lanes (1) or by one lane per tile (0)
+#ifndef GACT_SEED_WALK_TEAM
+#define GACT_SEED_WALK_TEAM 1
+#endif
+
+// timing experiments (wrong results; never in a shipped build): no traceback walk / no pointer stores
+#ifndef GACT_EXP_FAKE_WALK
+#define GACT_EXP_FAKE_WALK 0
+#endif
+#ifndef GACT_EXP_NO_STORE
+#define GACT_EXP_NO_STORE 0
+#endif
+#ifndef GACT_PTR_BUFFER_STORE
+#define GACT_PTR_BUFFER_STORE 0
+#endif
+#ifndef GACT_EXP_STORE_ONE
+#define GACT_EXP_STORE_ONE 0
+#endif
+#ifndef GACT_EXP_STORE_CONST
+#define GACT_EXP_STORE_CONST 0
+#endif
+#ifndef GACT_EXP_STORE_HOME
+#define GACT_EXP_STORE_HOME 0          // every flush block of a tile overwrites its block 0: same stores, no footprint
 #endif
 
 constexpr int kNegInf16 = -16384;
@@ -451,13 +473,13 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         if ((k & 7) == 7) {
 #pragma unroll
             for (int q = 0; q < QD; q++) {
-                qA[q * LANES] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
+                qA[q * kWsRow] = make_uint4(wordA(accO[4 * q], accF[4 * q]), wordA(accO[4 * q + 1], accF[4 * q + 1]),
                                             wordA(accO[4 * q + 2], accF[4 * q + 2]), wordA(accO[4 * q + 3], accF[4 * q + 3]));
-                qB[q * LANES] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
+                qB[q * kWsRow] = make_uint4(wordB(accO[4 * q], accF[4 * q]), wordB(accO[4 * q + 1], accF[4 * q + 1]),
                                            wordB(accO[4 * q + 2], accF[4 * q + 2]), wordB(accO[4 * q + 3], accF[4 * q + 3]));
             }
-            qA += QD * LANES;
-            qB += QD * LANES;
+            qA += QD * kWsRow;
+            qB += QD * kWsRow;
             if (AMAX) fold(k - 7);
         }
     }
@@ -492,9 +514,9 @@ __device__ __forceinline__ void dp_pass_p16(const P16Consts &kc, const int gl,
         auto just = [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); };
 #pragma unroll
         for (int q = 0; q < QD; q++) {
-            qA[q * LANES] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+            qA[q * kWsRow] = make_uint4(just(wordA(accO[4 * q], accF[4 * q])), just(wordA(accO[4 * q + 1], accF[4 * q + 1])),
                                         just(wordA(accO[4 * q + 2], accF[4 * q + 2])), just(wordA(accO[4 * q + 3], accF[4 * q + 3])));
-            qB[q * LANES] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+            qB[q * kWsRow] = make_uint4(just(wordB(accO[4 * q], accF[4 * q])), just(wordB(accO[4 * q + 1], accF[4 * q + 1])),
                                         just(wordB(accO[4 * q + 2], accF[4 * q + 2])), just(wordB(accO[4 * q + 3], accF[4 * q + 3])));
         }
     }
@@ -739,6 +761,29 @@ template <int C, int LANES = kGroup, bool TAG = false> struct UniformLayout {
 using WideLayout = UniformLayout<10, 32>;
 using WideLayoutTagged = UniformLayout<10, 32, true>;
 
+// span of the look-ahead walker's region cache (layouts of the linear-gap format name theirs) and the LDS scratch a
+// walker of layout L needs
+template <class L> constexpr int walk_span()
+{
+    if constexpr (L::kWalkFmt == 3) return L::kWalkSpan; else return 16;
+}
+// which walker a layout of the linear-gap format gets: the team of eight lanes where a wave holds four tiles and the
+// walk is 40 % of its time (wide layout: -4 % on the ONT-shape workload), one lane per tile where it holds eight and
+// the walk hides behind the other waves' passes (split layout: the team was +4 % there); -DGACT_WALK_TEAM=0 / 1 forces
+#ifndef GACT_WALK_TEAM
+#define GACT_WALK_TEAM -1
+#endif
+template <class L> constexpr bool walk_by_team()
+{
+    if constexpr (L::kWalkFmt != 3) return false;
+    else if (GACT_WALK_TEAM >= 0) return GACT_WALK_TEAM != 0;
+    else return L::kLanes == 32;
+}
+template <class L, bool TEAM> constexpr int walk_scratch_words()
+{
+    if constexpr (TEAM) return LaRegion<L::kWalkCols, L::kWalkQuads, walk_span<L>()>::kWords; else return kTbScratchWords;
+}
+
 // ---------------------------------------------------------------------------
 // Persistent main kernel: every group carries two candidates (slot A / slot B).
 // RAW: the sets hold bytes other than ACGT and are compared as raw bytes (see dp_pass_p16).
@@ -754,8 +799,12 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsOfWave;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
-    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
-    __shared__ uint32_t stage_lds[kGroupsPerBlock][StageGeom<L::kSlotsPerLane, LANES>::kWords];
+    // walker scratch (region cache) of the group's two tiles; the loader's staging area lives in the same bytes: a
+    // group's loader has finished before its pass starts, its walkers start after it
+    constexpr bool kTeamWalk = walk_by_team<L>();
+    constexpr int kStageHalf = (StageGeom<L::kSlotsPerLane, LANES>::kWords / kSlots + 3) & ~3;
+    constexpr int kScratchWords = walk_scratch_words<L, kTeamWalk>() > kStageHalf ? walk_scratch_words<L, kTeamWalk>() : kStageHalf;
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kScratchWords];
 
     WaveCtx w;
     {
@@ -770,11 +819,16 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
     uint8_t *q8 = ref8 + G::kRefBytes;
     const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (L::kRow0 - 1 - w.gl);
-    // a wave owns 8 tile workspaces of kp.ws_words; with 32 lanes per pair it has 4 tiles, each of them two
+    // a wave owns 8 tile workspaces' worth of kp.ws_words, and its tiles' words are interleaved in it: row =
+    // [tile A | tile B][the wave's 64 lanes] uint4 (kWsRow, gact_device.hpp), so a store instruction writes one KB
     constexpr int kWsPerTile = LANES / kGroup;
     static_assert(G::kWsWords <= kWsPerTile * Geometry<20>::kWsWords || L::kSlotsPerLane > 20, "workspace stride");
-    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words * kWsPerTile;
-    uint32_t *wsB = wsA + (size_t)kp.ws_words * kWsPerTile;
+#if GACT_EXP_STORE_HOME == 2
+    uint32_t *wsA = ws_all + (w.g * LANES) * 4;           // timing experiment: every wave of the chip on the same rows
+#else
+    uint32_t *wsA = ws_all + (size_t)(w.slot / kGroupsOfWave) * (8 * (size_t)kp.ws_words) + (w.g * LANES) * 4;
+#endif
+    uint32_t *wsB = wsA + 64 * 4;
 
     ChainState *st = chain_lds[group_in_block];
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
@@ -785,6 +839,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
 #ifdef GACT_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long tl_cyc0 = __builtin_amdgcn_s_memtime();
     unsigned long long tl_empty = 0;
 #endif
 
@@ -858,7 +913,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
 
         GACT_STAMP(t_b);
         uint32_t qb[L::kSlotsPerLane];
-        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb, stage_lds[group_in_block]);
+        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb, tb_lds[group_in_block][0]);
         wave_sync();
         GACT_STAMP(t_c);
 
@@ -896,7 +951,6 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
         // (the linear-gap format is walked by a team of eight lanes per tile: the first eight lanes of the tile's half
         // of the group, gact_chain.hpp walk_chain_lin_team; the other formats by one lane per tile, lanes 0 and 1)
-        constexpr bool kTeamWalk = L::kWalkFmt == 3 && !GACT_WALK_SINGLE_LANE;
         constexpr int kWalkLanes = kTeamWalk ? LANES / kSlots : 1;         // lane h * kWalkLanes holds the walk's results
         {
             const int h = kTeamWalk ? w.gl / kWalkLanes : (w.gl & 1);
@@ -907,15 +961,21 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
             const uint8_t *qrow = q8 + h * G::kTileMax;
             int l0, c0, k0;
             L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
-            if constexpr (kTeamWalk) {
+            if constexpr (kTeamWalk && GACT_EXP_FAKE_WALK) {
+                // timing experiment only (results are wrong): no walk, every tile taken as a diagonal of `early` steps
                 wk.load(st[h]);
-                walk_chain_lin_team<L::kWalkCols, L::kWalkQuads, LANES>(tb_lds[group_in_block][h], mine, Rh, Qh, l0, c0, k0, kp.early,
+                ref_steps = query_steps = imin(kp.early, imin(Rh, Qh));
+                nst = mine ? 2 * ref_steps : 0;
+                wk.score += ref_steps;
+            } else if constexpr (kTeamWalk) {
+                wk.load(st[h]);
+                walk_chain_lin_team<L::kWalkCols, L::kWalkQuads, kWsRow, walk_span<L>()>(tb_lds[group_in_block][h], mine, Rh, Qh, l0, c0, k0, kp.early,
                                                                         rrow, 2, qrow, kp, wk, ref_steps, query_steps, nst,
                                                                         h ? v0_h[1] : v0_h[0], h ? wsB : wsA, ws_all);
             } else if (mine) {
                 const ChainState &s = st[h];
                 wk.load(s);
-                walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, LANES>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
+                walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, kWsRow>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
                                                            query_steps, nst, h ? v0_h[1] : v0_h[0], ws_all);
             }
@@ -948,6 +1008,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         if (wv < 4096) {
             g_timeline[4 * wv] = tl_start; g_timeline[4 * wv + 1] = tl_empty;
             g_timeline[4 * wv + 2] = __builtin_amdgcn_s_memrealtime(); g_timeline[4 * wv + 3] = stamp_acc[6];
+            g_wave_cycles[wv] = __builtin_amdgcn_s_memtime() - tl_cyc0;
         }
     }
 #endif
@@ -978,16 +1039,18 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
     constexpr int kGroupsPerBlock = (kBlockThreads / 64) * kGroupsPerWave;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kGroupsPerBlock * G::kGroupLds];
     __shared__ ChainState chain_lds[kGroupsPerBlock][kSlots];
-    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kTbScratchWords];
-    __shared__ uint32_t stage_lds[kGroupsPerBlock][StageGeom<C, kGroup>::kWords];
+    // (walker scratch and the loader's staging area in the same bytes, as in extend_p16_kernel)
+    constexpr int kStageHalf = (StageGeom<C, kGroup>::kWords / kSlots + 3) & ~3;
+    constexpr int kScratchWords = kTbScratchWords > kStageHalf ? kTbScratchWords : kStageHalf;
+    __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kScratchWords];
 
     const WaveCtx w = wave_ctx();
     const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
     uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
     uint8_t *q8 = ref8 + G::kRefBytes;
     const uint16_t *ref16_lane = reinterpret_cast<const uint16_t *>(ref8) + (L::kRow0 - 1 - w.gl);
-    uint32_t *wsA = ws_all + (size_t)(w.slot * kSlots) * kp.ws_words;
-    uint32_t *wsB = wsA + kp.ws_words;
+    uint32_t *wsA = ws_all + (size_t)(w.slot / kGroupsPerWave) * (8 * (size_t)kp.ws_words) + (w.g * kGroup) * 4;     // (see extend_p16_kernel)
+    uint32_t *wsB = wsA + 64 * 4;
 
     ChainState *st = chain_lds[group_in_block];
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; st[w.gl].comp = 0; }
@@ -1034,7 +1097,7 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
         const int T_end = wave_max4(imax(L::last_step(pt.R[0], pt.Q[0]), L::last_step(pt.R[1], pt.Q[1])));
 
         uint32_t qb[C];
-        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb, stage_lds[group_in_block]);
+        L::template load<RAW>(refs, qfwd, qrc, pt, w.gl, ref8, q8, qb, tb_lds[group_in_block][0]);
         wave_sync();
 
         P16Best pb;
@@ -1064,7 +1127,7 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
         int ref_steps = 0, query_steps = 0, nst = 0;
         ScoreWalk wk;
         wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
-        constexpr bool kTeamWalk = LIN && !GACT_WALK_SINGLE_LANE;          // (see extend_p16_kernel)
+        constexpr bool kTeamWalk = LIN && GACT_SEED_WALK_TEAM;              // (see extend_p16_kernel)
         constexpr int kWalkLanes = kTeamWalk ? kGroup / kSlots : 1;
         {
             const int h = kTeamWalk ? w.gl / kWalkLanes : (w.gl & 1);
@@ -1075,12 +1138,12 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
             const int l0 = (imax(j0, 1) - 1) / C;
             // (FMT 3 walkers start from the score of their cell: the arg-max)
             if constexpr (kTeamWalk) {
-                walk_chain_lin_team<C, ((C + 1) / 2 + 3) / 4, kGroup>(tb_lds[group_in_block][h], mine, i0, j0, l0, (j0 - 1) - l0 * C,
+                walk_chain_lin_team<C, ((C + 1) / 2 + 3) / 4, kWsRow, 16>(tb_lds[group_in_block][h], mine, i0, j0, l0, (j0 - 1) - l0 * C,
                                                                       i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
                                                                       kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0],
                                                                       h ? wsB : wsA, ws_all);
             } else if (mine) {
-                walk_chain<C, LIN ? 3 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
+                walk_chain<C, LIN ? 3 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4, kWsRow>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
                                                   i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
                                                   s.phase, kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0], ws_all);
             }

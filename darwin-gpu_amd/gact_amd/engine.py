@@ -207,6 +207,7 @@ class Engine:
         self.h = C.c_void_p()
         self._check(self.L.gact_hip_create(C.byref(self.p), C.byref(self.h)))
         self.tile_size = tile_size
+        self.tile_overlap = tile_overlap
 
     def _check(self, rc):
         if rc < 0:

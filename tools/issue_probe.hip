@@ -86,6 +86,26 @@ PROBE(p_chain_sub_max,
       asm volatile("v_sub_u32 %0, %1, %2\n\tv_pk_max_i16 %1, %0, %2\n\tv_sub_u32 %0, %1, %2\n\tv_pk_max_i16 %1, %0, %2"
                    : "+v"(a[2]), "+v"(a[0]), "+v"(x));)
 
+// round 3: the half-precision maxima that order positive int16 like integers, and the score step built on them
+PROBE(p_pk_maximum3_f16, asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));, asm volatile("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(a[0]) : "v"(x), "v"(y));)
+PROBE(p_pk_max_f16, asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[k]) : "v"(x));, asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(a[0]) : "v"(x));)
+PROBE(p_pk_max_u16, asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[k]) : "v"(x));, asm volatile("v_pk_max_u16 %0, %0, %1" : "+v"(a[0]) : "v"(x));)
+PROBE(p_max3_i32, asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));, asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[0]) : "v"(x), "v"(y));)
+PROBE(p_max3_i16, asm volatile("v_max3_i16 %0, %0, %1, %2" : "+v"(a[k]) : "v"(x), "v"(y));, asm volatile("v_max3_i16 %0, %0, %1, %2" : "+v"(a[0]) : "v"(x), "v"(y));)
+PROBE(p_pk_sub_i16, asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[k]) : "v"(x));, asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[0]) : "v"(x));)
+// perm, add, max3 | sub, max   (5 instructions per k)
+PROBE(p_lin_slot5,
+      asm volatile("v_perm_b32 %0, %1, %2, %0\n\tv_add_u32 %0, %0, %1\n\tv_pk_maximum3_f16 %0, %0, %2, %1\n\t"
+                   "v_sub_u32 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[k]) : "v"(x), "v"(y));,
+      asm volatile("v_perm_b32 %0, %1, %2, %0\n\tv_add_u32 %0, %0, %1\n\tv_pk_maximum3_f16 %0, %0, %2, %1\n\t"
+                   "v_sub_u32 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[0]) : "v"(x), "v"(y));)
+// perm, add, max, max | sub, max   (6 instructions per k: what the pass was before the fold)
+PROBE(p_lin_slot6,
+      asm volatile("v_perm_b32 %0, %1, %2, %0\n\tv_add_u32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1\n\t"
+                   "v_sub_u32 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[k]) : "v"(x), "v"(y));,
+      asm volatile("v_perm_b32 %0, %1, %2, %0\n\tv_add_u32 %0, %0, %1\n\tv_pk_max_i16 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1\n\t"
+                   "v_sub_u32 %0, %0, %2\n\tv_pk_max_i16 %0, %0, %1" : "+v"(a[0]) : "v"(x), "v"(y));)
+
 struct Cell { double wave_cycles, simd_cycles; };
 
 template <class K> Cell run(K kern, int waves_per_simd, int instr_per_k)
@@ -127,14 +147,24 @@ template <class K> Cell run(K kern, int waves_per_simd, int instr_per_k)
         printf("}}");                                                                                  \
     }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool only_new = argc > 1;          // any argument: the rows added in round 3 only
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, 0) != hipSuccess) { fprintf(stderr, "no device\n"); return 1; }
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d,\n", p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000);
     printf(" \"note\": \"cycles[w] = [shader clocks between two issues of one wave, the same divided by w = the SIMD's issue "
            "interval], w = resident waves per SIMD; s_memtime inside the wave, median over all waves\",\n \"rows\": [\n");
     bool first = true;
+    ROW("v_pk_maximum3_f16", p_pk_maximum3_f16, 1)
+    ROW("v_pk_max_f16", p_pk_max_f16, 1)
+    ROW("v_pk_max_u16", p_pk_max_u16, 1)
+    ROW("v_max3_i32", p_max3_i32, 1)
+    ROW("v_max3_i16", p_max3_i16, 1)
+    ROW("v_pk_sub_i16", p_pk_sub_i16, 1)
+    ROW("linear-gap slot, 5 instructions (perm, add, maximum3 | sub, max)", p_lin_slot5, 5)
+    ROW("linear-gap slot, 6 instructions (perm, add, max, max | sub, max)", p_lin_slot6, 6)
+    if (only_new) { printf("\n ]}\n"); return 0; }
     ROW("v_add_u32", p_add_u32, 1)
     ROW("v_max_i32", p_max_i32, 1)
     ROW("v_pk_add_i16", p_pk_add_i16, 1)

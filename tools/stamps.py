@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(ROOT, "darwin-gpu_amd"))
 import numpy as np
 from gact_amd import engine, workload
 
-lib = os.path.join(ROOT, "darwin-gpu_amd", "libgact_hip_stamps.so")
+lib = os.environ.get("GACT_STAMPS_LIB") or os.path.join(ROOT, "darwin-gpu_amd", "libgact_hip_stamps.so")
 if not os.path.exists(lib):
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGACT_STAMPS",
                            "-I" + os.path.join(ROOT, "include"), "-o", lib,
@@ -42,6 +42,13 @@ tl = (C.c_ulonglong * (4 * nw))()
 eng.L.gact_hip_debug_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 eng.L.gact_hip_debug_timeline(eng.h, tl, nw)
 t = np.array(list(tl), dtype=np.float64).reshape(nw, 4)
+cyc = (C.c_ulonglong * nw)()
+eng.L.gact_hip_debug_wave_cycles.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+eng.L.gact_hip_debug_wave_cycles(eng.h, cyc, nw)
+cyc = np.array(list(cyc), dtype=np.float64)
+ok = (t[:, 2] > t[:, 0]) & (cyc > 0)
+print("in-kernel clock (wave lifetimes: s_memtime cycles / s_memrealtime at 100 MHz): median %.0f MHz (p10 %.0f, p90 %.0f)" %
+      tuple(np.percentile(cyc[ok] / (t[ok, 2] - t[ok, 0]) * 100.0, [50, 10, 90]).tolist()))
 t = t[t[:, 2] > 0]
 t0 = t[:, 0].min()
 ms = lambda x: (x - t0) / 1e5          # 100 MHz

@@ -627,7 +627,29 @@ struct ChainQueues {
     int live_stride;
     ChainState *states;          // their chain states
     int *longest_now;            // [kEpochs] longest remaining chain (bases) any wave reported, per time slice
+    // routing by read content (align.cpp:134 compares raw bytes: N == N, case matters): route_kernel (gact_kernels.hpp)
+    // sorts the candidates of a run into those whose two reads are plain A/C/G/T and the rest; a seed launch then takes
+    // one of the two lists
+    const int *list_count;       // null: the seed launch takes the candidates [first, first + n) themselves
+    const int *list;             // candidate indices
 };
+
+// next candidate of a seed launch into s (group-uniform; `leader` = the group's lane 0 does the atomic, bcast = a
+// functor that broadcasts its value over the group).  Returns false when the list is exhausted.
+template <class Bcast>
+__device__ __forceinline__ bool seed_pop(ChainState &s, const ChainQueues &cq, bool leader, Bcast bcast, const gact_candidate *cands,
+                                         int first_cand, int n, int rc_from, const SeqSetDev &refs, const SeqSetDev &qfwd,
+                                         const SeqSetDev &qrc)
+{
+    const int total = cq.list_count ? *cq.list_count : n;
+    int idx = 0;
+    if (leader) idx = atomicAdd(cq.pop_seed, 1);
+    idx = bcast(idx);
+    if (idx >= total) return false;
+    const int cand = cq.list_count ? cq.list[idx] : first_cand + idx;
+    chain_begin(s, cand, cands[cand], refs, qfwd, qrc, rc_from);
+    return true;
+}
 
 // The main launch's waves rank themselves against the longest chain still running anywhere: every wave posts
 // its longest remaining chain into the slice of the 100 MHz clock it is in and reads the previous slice

@@ -41,6 +41,7 @@ struct SeqSetDev {
     const int64_t *offsets;   // n+1
     int32_t n;
     int32_t use_raw;          // 1: compare raw bytes (set holds non-ACGT)
+    const int32_t *other;     // per sequence: 1 = holds a byte other than A/C/G/T (pack_kernel); the routing of gact_chain.hpp
 };
 
 struct KParams {

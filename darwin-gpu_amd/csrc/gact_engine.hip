@@ -51,6 +51,7 @@ struct SeqSet {
     uint32_t *d_packed = nullptr;
     uint8_t *d_raw = nullptr;
     int64_t *d_offsets = nullptr;
+    int32_t *d_other = nullptr;   // per sequence: holds a byte other than A/C/G/T
     std::vector<int64_t> h_offsets;
     int32_t n = 0;
     int64_t total = 0;
@@ -63,6 +64,7 @@ struct SeqSet {
         gact::SeqSetDev d;
         d.packed = d_packed; d.raw = d_raw; d.offsets = d_offsets; d.n = n;
         d.use_raw = use_raw ? 1 : 0;
+        d.other = has_other ? d_other : nullptr;
         return d;
     }
     // The tile loaders issue their loads unpredicated (idle slots read position 0 of
@@ -77,7 +79,8 @@ struct SeqSet {
         if (d_packed) (void)hipFree(d_packed);
         if (d_raw) (void)hipFree(d_raw);
         if (d_offsets) (void)hipFree(d_offsets);
-        d_packed = nullptr; d_raw = nullptr; d_offsets = nullptr;
+        if (d_other) (void)hipFree(d_other);
+        d_packed = nullptr; d_raw = nullptr; d_offsets = nullptr; d_other = nullptr;
         cap_bases = cap_seqs = 0; n = 0; total = 0;
     }
 };
@@ -113,6 +116,8 @@ struct Slot {
     DevBuf<gact_overlap> overlaps;
     int *d_counter = nullptr;            // see queues()
     DevBuf<int> live;
+    DevBuf<int> deferred;                // route_kernel's two candidate lists (launch_extend), n entries each
+    int routed_raw = 0;                  // how many candidates the last run aligned from raw bytes beside the 2-bit launches
     DevBuf<gact::ChainState> chain_states;
     uint32_t *d_ws = nullptr;
     int *d_flags = nullptr;
@@ -176,6 +181,7 @@ struct gact_hip_engine {
     bool lin = false;           // linear gaps (open == extend == mismatch): the drifted pass of gact_lin.hpp on 2-bit sets
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
+    bool route_other = true;    // GACT_HIP_NO_ROUTING unset: raw-byte kernels only for candidates with a non-ACGT read
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool static_prio = false;   // GACT_HIP_STATIC_PRIO: fixed thresholds instead of the ranking (read once, at create)
     uint32_t poison = 0;        // GACT_HIP_POISON_WS=<seed>: the workspace is filled with a seeded pattern before every launch
@@ -239,8 +245,10 @@ int reserve_set(SeqSet &s, int64_t total, int32_t n_seqs)
     const size_t need_seqs = (size_t)n_seqs + 2;
     if (need_seqs > s.cap_seqs) {
         if (s.d_offsets) (void)hipFree(s.d_offsets);
-        s.d_offsets = nullptr; s.cap_seqs = 0;
+        if (s.d_other) (void)hipFree(s.d_other);
+        s.d_offsets = nullptr; s.d_other = nullptr; s.cap_seqs = 0;
         HIP_TRY(hipMalloc((void **)&s.d_offsets, need_seqs * sizeof(int64_t)));
+        HIP_TRY(hipMalloc((void **)&s.d_other, need_seqs * sizeof(int32_t)));
         s.cap_seqs = need_seqs;
     }
     return 0;
@@ -272,8 +280,9 @@ int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, c
     const int64_t n_words = (total + 15) / 16 + 2;
     const int threads = 256;
     const int blocks = (int)std::min<int64_t>((n_words + threads - 1) / threads, 4096);
+    HIP_TRY(hipMemsetAsync(s.d_other, 0, (size_t)(n_seqs + 1) * sizeof(int32_t), sl.stream));
     hipLaunchKernelGGL(gact::pack_kernel, dim3(std::max(blocks, 1)), dim3(threads), 0, sl.stream,
-                       s.d_raw, total, s.d_packed, n_words, sl.d_flags);
+                       s.d_raw, total, s.d_packed, n_words, sl.d_flags, s.d_offsets, n_seqs, s.d_other);
     HIP_TRY(hipGetLastError());
     int flags = 0;
     HIP_TRY(hipMemcpyAsync(&flags, sl.d_flags, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
@@ -298,7 +307,7 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
     return 0;
 }
 
-// d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [8..8+kBuckets) bucket_count,
+// d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [4] / [5] candidates routed to the 2-bit / the raw-byte launches, [8..8+kBuckets) bucket_count,
 // [8+kBuckets..8+2*kBuckets) bucket_pop
 constexpr int kCounterInts = 8 + 2 * gact::kBuckets + gact::kEpochs;
 
@@ -313,6 +322,8 @@ gact::ChainQueues queues(Slot &sl)
     q.live_stride = (int)(sl.live.cap / gact::kBuckets);
     q.states = sl.chain_states.p;
     q.longest_now = sl.d_counter + 8 + 2 * gact::kBuckets;
+    q.list_count = nullptr;
+    q.list = nullptr;
     return q;
 }
 
@@ -324,13 +335,12 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     const SeqSet &rs = e->sets[GACT_SET_REF];
     const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
     const bool need_f = first < rc_from, need_r = first + n > rc_from;
-    const bool raw = rs.has_other || (need_f && qf.has_other) || (need_r && qr.has_other);
-    const int groups_needed = e->p16 ? (n + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave)
-                                     : (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
-    const int seed_waves = (n + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
-    const int seed_blocks = std::max(1, std::min((seed_waves + 3) / 4, e->grid_blocks));
-    const int main_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->grid_blocks));
-    // DP issue priority by remaining chain length (extend_p16_kernel): thirds of the longest possible chain
+    // Sets that hold bytes other than A/C/G/T (N, lower case) are compared as raw bytes like align.cpp:134.  With the
+    // packed kernels that is decided per CANDIDATE: the launches on the 2-bit image put off every candidate one of whose
+    // two reads holds such a byte (SeqSetDev::other, from pack_kernel), and a second pair of launches on the raw bytes
+    // takes those -- one soft-masked read no longer moves a whole launch onto the slower kernels.
+    const bool any_other = rs.has_other || (need_f && qf.has_other) || (need_r && qr.has_other);
+    const bool mixed = any_other && e->p16 && e->route_other;
     gact::KParams kp = e->kp;
     const int64_t longest = std::min(rs.max_len, std::max(need_f ? qf.max_len : 0, need_r ? qr.max_len : 0));
     // GACT_HIP_STATIC_PRIO: thirds of the longest possible chain instead of the ranking against what is running
@@ -338,40 +348,76 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     kp.prio_bases[0] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(longest / 3, 0x7fffffff) : 0;
     const int rank16 = e->rank16;                    // above 3/4 of the longest running chain: priority 2, above 1/2: 1
     kp.prio_bases[1] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : rank16;
-    // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
-    if (e->seed16) {
-        int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
-        auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
-        if constexpr (C == 20) {                     // the linear-gap seed pass exists for the 20-column geometry only
-            if (!raw && e->lin) {
-                k16 = gact::seed_p16_kernel<C, false, true>;
-                blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_lin_grid_blocks));
-            }
-        }
-        hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
-                           kp, e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from,
-                           same_file, sl.overlaps.p, queues(sl), sl.d_ws);
-    } else {
-        hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
-                           kp, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), sl.cands.p, first, n, rc_from, same_file,
-                           sl.overlaps.p, queues(sl), e->p16 ? 1 : 0, sl.d_ws);
-    }
-    HIP_TRY(hipGetLastError());
     sl.two_phase = e->p16;
-    if (e->p16) {
-        HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
+    sl.routed_raw = 0;
+
+    // one seed launch + (packed kernels) one main launch over `count` candidates at most
+    // GACT_HIP_TRACE: every launch named on stderr and waited for (a faulting kernel is the last one named)
+    static const bool trace = getenv("GACT_HIP_TRACE") != nullptr;
+    auto traced = [&](const char *what, int blocks, int count) -> int {
+        if (!trace) return 0;
+        fprintf(stderr, "[gact_hip] %s: %d blocks, %d candidates (sets other %p %p %p, n %d %d %d, deferred list %p cap %zu) ... ", what, blocks, count,
+                (void *)rs.dev(false).other, (void *)qf.dev_or(false, rs).other, (void *)qr.dev_or(false, rs).other, rs.n, qf.n, qr.n,
+                (void *)sl.deferred.p, sl.deferred.cap);
+        fflush(stderr);
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+        int dbg[8];
+        HIP_TRY(hipMemcpy(dbg, sl.d_counter, sizeof dbg, hipMemcpyDeviceToHost));
+        fprintf(stderr, "done (popped %d; routed %d to the 2-bit, %d to the raw-byte launches)\n", dbg[0], dbg[4], dbg[5]);
+        return 0;
+    };
+    auto run_pass = [&](bool raw, const int *list, const int *list_count, int count, bool first_pass) -> int {
+        const int groups_needed = e->p16 ? (count + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave)
+                                         : (count + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
+        const int seed_waves = (count + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
+        const int seed_blocks = std::max(1, std::min((seed_waves + 3) / 4, e->grid_blocks));
+        const int main_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->grid_blocks));
+        const gact::SeqSetDev d_rs = rs.dev(raw), d_qf = qf.dev_or(raw, rs), d_qr = qr.dev_or(raw, rs);
+        gact::ChainQueues cq = queues(sl);
+        cq.list = list; cq.list_count = list_count;
+        if (trace) {
+            fprintf(stderr, "[gact_hip] pass raw=%d listed=%d count=%d first=%d n=%d rc_from=%d\n", (int)raw, list != nullptr, count, first, n, rc_from);
+            fprintf(stderr, "[gact_hip]   ws %p + %zu MiB, counter %p, cands %p (%zu), overlaps %p, live %p (%zu), states %p (%zu x %zu B)\n", (void *)sl.d_ws,
+                    e->ws_words_total * 4 >> 20, (void *)sl.d_counter, (void *)sl.cands.p, sl.cands.cap, (void *)sl.overlaps.p, (void *)sl.live.p,
+                    sl.live.cap, (void *)sl.chain_states.p, sl.chain_states.cap, sizeof(gact::ChainState));
+            fprintf(stderr, "[gact_hip]   ref raw %p packed %p offsets %p (%lld bases), query %p %p, rc %p %p\n", (void *)rs.d_raw, (void *)rs.d_packed,
+                    (void *)rs.d_offsets, (long long)rs.total, (void *)qf.d_raw, (void *)qf.d_packed, (void *)qr.d_raw, (void *)qr.d_packed);
+        }
+        // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
+        if (e->seed16) {
+            int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
+            auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
+            if constexpr (C == 20) {                     // the linear-gap seed pass exists for the 20-column geometry only
+                if (!raw && e->lin) {
+                    k16 = gact::seed_p16_kernel<C, false, true>;
+                    blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_lin_grid_blocks));
+                }
+            }
+            hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
+                               kp, e->kc, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from,
+                               same_file, sl.overlaps.p, cq, sl.d_ws);
+        } else {
+            hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
+                               kp, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file,
+                               sl.overlaps.p, cq, e->p16 ? 1 : 0, sl.d_ws);
+        }
+        HIP_TRY(hipGetLastError());
+        { int trc = traced(raw ? "seed launch (raw bytes)" : "seed launch (2-bit)", seed_blocks, count); if (trc) return trc; }
+        if (!e->p16) return 0;
+        if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
         { int prc = poison_ws(e, sl, 0x5bd1e995u); if (prc) return prc; }      // the main launch reads nothing the seed launch stored
         // fewer chains than the narrow layouts have tile slots: the launch lasts as long as its longest chain, so
         // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
         const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
-        sl.wide = C == 20 && e->wide >= 0 && (e->wide > 0 || n <= narrow_slots);
+        const bool wide = C == 20 && e->wide >= 0 && (e->wide > 0 || count <= narrow_slots);
         using gact::extend_p16_kernel;
         const bool tg = e->tagged;
-        sl.lin = e->lin && !raw && (sl.wide || e->split);
-        auto km = sl.lin ? (sl.wide ? extend_p16_kernel<gact::WideLayoutLin, false>
-                                    : extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>)
-                : sl.wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
-                                : (raw ? extend_p16_kernel<gact::WideLayout, true> : extend_p16_kernel<gact::WideLayout, false>))
+        const bool lin = e->lin && !raw && (wide || e->split);
+        if (first_pass) { sl.wide = wide; sl.lin = lin; }
+        auto km = lin ? (wide ? extend_p16_kernel<gact::WideLayoutLin, false>
+                              : extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>)
+                : wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
+                             : (raw ? extend_p16_kernel<gact::WideLayout, true> : extend_p16_kernel<gact::WideLayout, false>))
                 : e->split ? (tg ? (raw ? extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
                                         : extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>)
                                  : (raw ? extend_p16_kernel<gact::SplitLayout<7, 13>, true>
@@ -384,15 +430,36 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // at one instruction per ~11 cycles with one neighbour on its SIMD, ~15 with two (8 alone, but then half the
         // VALU idles): ONT-shape workload 150 ms -> 116 ms; one wave per SIMD: 132 ms
         const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : 2;
-        const int wide_cap = std::min(sl.lin ? e->wide_lin_grid_blocks : e->grid_blocks, per_cu * e->prop.multiProcessorCount);
-        const int wide_blocks = std::max(1, std::min((n + 15) / 16, wide_cap));             // 4 tiles per wave
+        const int wide_cap = std::min(lin ? e->wide_lin_grid_blocks : e->grid_blocks, per_cu * e->prop.multiProcessorCount);
+        const int wide_blocks = std::max(1, std::min((count + 15) / 16, wide_cap));             // 4 tiles per wave
         const int lin_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->lin_grid_blocks));
-        hipLaunchKernelGGL(km, dim3(sl.wide ? wide_blocks : (sl.lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, sl.stream, kp,
-                           e->kc, rs.dev(raw), qf.dev_or(raw, rs), qr.dev_or(raw, rs), same_file, sl.overlaps.p,
-                           queues(sl), sl.d_ws);
+        hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, sl.stream, kp,
+                           e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, sl.d_ws);
         HIP_TRY(hipGetLastError());
+        return traced(raw ? "main launch (raw bytes)" : "main launch (2-bit)", wide ? wide_blocks : (lin ? lin_blocks : main_blocks), count);
+    };
+
+    if (!mixed) return run_pass(any_other, nullptr, nullptr, n, true);
+    // the candidates sorted by what their two reads hold: two lists, their lengths back on the host (they decide grids
+    // and layouts: the only host wait of a run, and only of a run over sets with such reads)
+    const gact::SeqSetDev o_rs = rs.dev(false), o_qf = qf.dev_or(false, rs), o_qr = qr.dev_or(false, rs);
+    hipLaunchKernelGGL(gact::route_kernel, dim3(std::max(1, std::min((n + 255) / 256, 1024))), dim3(256), 0, sl.stream, sl.cands.p, first, n,
+                       rc_from, o_rs.other, need_f ? o_qf.other : nullptr, need_r ? o_qr.other : nullptr, sl.deferred.p, sl.d_counter + 4);
+    HIP_TRY(hipGetLastError());
+    int routed[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(routed, sl.d_counter + 4, sizeof routed, hipMemcpyDeviceToHost, sl.stream));
+    HIP_TRY(hipStreamSynchronize(sl.stream));
+    sl.routed_raw = routed[1];
+    int rc = 0;
+    if (routed[0] > 0 && (rc = run_pass(false, sl.deferred.p, sl.d_counter + 4, routed[0], true))) return rc;
+    if (routed[1] == 0) return 0;
+    if (routed[0] > 0) {
+        // the queues again from empty (the seed launches' cell counter and the two lists stay)
+        HIP_TRY(hipMemsetAsync(sl.d_counter, 0, sizeof(int), sl.stream));
+        HIP_TRY(hipMemsetAsync(sl.d_counter + 8, 0, (kCounterInts - 8) * sizeof(int), sl.stream));
+        { int prc = poison_ws(e, sl, 0x1b873593u); if (prc) return prc; }
     }
-    return 0;
+    return run_pass(true, sl.deferred.p + n, sl.d_counter + 5, routed[1], routed[0] == 0);
 }
 
 template <int C> int occupancy_blocks(int *out)
@@ -547,6 +614,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
              getenv("GACT_HIP_NO_LIN") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
+    e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
     if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
     if (const char *v = getenv("GACT_HIP_POISON_WS")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
@@ -630,7 +698,7 @@ void gact_hip_destroy(gact_hip_engine *e)
     for (auto &sl : e->slots) {
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
         sl.tiles.release(); sl.results.release(); sl.states.release();
-        sl.cands.release(); sl.overlaps.release(); sl.live.release(); sl.chain_states.release();
+        sl.cands.release(); sl.overlaps.release(); sl.live.release(); sl.chain_states.release(); sl.deferred.release();
         sl.inline_ref.release(); sl.inline_query.release();
         if (sl.d_counter) (void)hipFree(sl.d_counter);
         if (sl.d_flags) (void)hipFree(sl.d_flags);
@@ -700,8 +768,9 @@ int gact_hip_derive_revcomp(gact_hip_engine *e)
                        qf.d_offsets, qf.n, qf.total, qr.d_raw, sl.d_flags);
     const int64_t n_words = (qf.total + 15) / 16 + 2;
     const int pblocks = (int)std::min<int64_t>((n_words + threads - 1) / threads, 4096);
+    HIP_TRY(hipMemsetAsync(qr.d_other, 0, (size_t)(qf.n + 1) * sizeof(int32_t), sl.stream));
     hipLaunchKernelGGL(gact::pack_kernel, dim3(std::max(pblocks, 1)), dim3(threads), 0, sl.stream, qr.d_raw, qf.total,
-                       qr.d_packed, n_words, sl.d_flags);
+                       qr.d_packed, n_words, sl.d_flags, qr.d_offsets, qf.n, qr.d_other);
     HIP_TRY(hipGetLastError());
     int flags = 0;
     HIP_TRY(hipMemcpyAsync(&flags, sl.d_flags, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
@@ -791,7 +860,8 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
         if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0)
             return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
     }
-    if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve((size_t)n * gact::kBuckets) || sl.chain_states.reserve(n))
+    if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve((size_t)n * gact::kBuckets) || sl.chain_states.reserve(n) ||
+        sl.deferred.reserve(2 * (size_t)n))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     sl.n_cands = 0;
     sl.h_cands.assign(cands, cands + n);
@@ -979,6 +1049,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     st->seed_packed16 = (sl.two_phase && e->seed16) ? 1 : 0;
     st->tagged_pointers = (sl.two_phase && e->tagged) ? 1 : 0;
     st->linear_gap = (sl.two_phase && sl.lin) ? 1 : 0;
+    st->raw_candidates = sl.routed_raw;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));
         HIP_TRY(hipEventElapsedTime(&st->main_ms, sl.ev_mid, sl.ev1));

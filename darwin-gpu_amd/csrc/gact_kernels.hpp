@@ -168,11 +168,8 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_kernel(
         for (int guard = 0; guard < 3 && !pk.have; guard++) {
             if (s.phase == 2) {
                 if (exhausted) break;
-                int idx = 0;
-                if (w.gl == 0) idx = atomicAdd(cq.pop_seed, 1);
-                idx = __shfl(idx, 0, kGroup);
-                if (idx >= n) { exhausted = true; break; }
-                chain_begin(s, first_cand + idx, cands[first_cand + idx], refs, qfwd, qrc, rc_from);
+                if (!seed_pop(s, cq, w.gl == 0, [](int v) { return __shfl(v, 0, kGroup); }, cands, first_cand, n, rc_from, refs, qfwd,
+                              qrc)) { exhausted = true; break; }
             }
             pk = chain_pick(s, kp, same_file, out, w.gl == 0);
             if (!pk.have && seed_mode && w.gl == 0)
@@ -262,19 +259,36 @@ __device__ __forceinline__ uint32_t base_code(uint32_t b, bool &bad)
     }
 }
 
+// seq_other[r] = 1 for every sequence r that holds such a byte (a word with one looks its sequences up by bisection:
+// rare).  A candidate whose two reads are clean is aligned from the 2-bit image even when others of its set are not.
 __global__ void pack_kernel(const uint8_t *__restrict__ raw, int64_t n_bases,
-                            uint32_t *__restrict__ packed, int64_t n_words, int *__restrict__ flags)
+                            uint32_t *__restrict__ packed, int64_t n_words, int *__restrict__ flags,
+                            const int64_t *__restrict__ offsets, int n_seqs, int32_t *__restrict__ seq_other)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (int64_t wi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; wi < n_words; wi += stride) {
         uint32_t word = 0;
         const int64_t b0 = wi * 16;
+        bool bad_here = false;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int64_t p = b0 + k;
-            if (p < n_bases) word |= base_code(raw[p], bad) << (2 * k);
+            if (p < n_bases) {
+                bool b = false;
+                word |= base_code(raw[p], b) << (2 * k);
+                if (b && seq_other) {
+                    int lo = 0, hi = n_seqs - 1;         // last sequence with offsets[r] <= p
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (offsets[mid] <= p) lo = mid; else hi = mid - 1;
+                    }
+                    seq_other[lo] = 1;
+                }
+                bad_here |= b;
+            }
         }
+        bad |= bad_here;
         packed[wi] = word;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
@@ -307,6 +321,25 @@ __global__ void revcomp_kernel(const uint8_t *__restrict__ raw, const int64_t *_
         out[offsets[lo] + (offsets[lo + 1] - 1 - p)] = c;
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flags, 2);
+}
+
+// ---------------------------------------------------------------------------
+// Routing by read content: candidates [first, first + n) sorted into two index lists, lists[0 .. n) = both reads plain
+// A/C/G/T (aligned from the 2-bit image), lists[n .. 2n) = one of them holds another byte (aligned from the raw bytes,
+// align.cpp:134); counts[0], counts[1] their lengths.  The order inside a list is whatever the atomics make it: a
+// candidate's record does not depend on where it sits in a list.
+__global__ void route_kernel(const gact_candidate *__restrict__ cands, int first, int n, int rc_from,
+                             const int32_t *__restrict__ ref_other, const int32_t *__restrict__ qf_other,
+                             const int32_t *__restrict__ qr_other, int *__restrict__ lists, int *__restrict__ counts)
+{
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const int cand = first + k;
+        const gact_candidate c = cands[cand];
+        const int32_t *qo = cand >= rc_from ? qr_other : qf_other;
+        const bool dirty = (ref_other && ref_other[c.ref_id]) || (qo && qo[c.query_id]);
+        lists[(dirty ? n : 0) + atomicAdd(&counts[dirty ? 1 : 0], 1)] = cand;
+    }
 }
 
 // ---------------------------------------------------------------------------

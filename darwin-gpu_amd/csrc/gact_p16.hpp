@@ -1071,11 +1071,8 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
             for (int guard = 0; guard < 3 && !pk.have; guard++) {
                 if (s.phase == 2) {
                     if (exhausted) break;
-                    int idx = 0;
-                    if (w.gl == 0) idx = atomicAdd(cq.pop_seed, 1);
-                    idx = __shfl(idx, 0, kGroup);
-                    if (idx >= n) { exhausted = true; break; }
-                    chain_begin(s, first_cand + idx, cands[first_cand + idx], refs, qfwd, qrc, rc_from);
+                    if (!seed_pop(s, cq, w.gl == 0, [](int v) { return __shfl(v, 0, kGroup); }, cands, first_cand, n, rc_from, refs,
+                                  qfwd, qrc)) { exhausted = true; break; }
                 }
                 pk = chain_pick(s, kp, same_file, out, w.gl == 0);
                 if (!pk.have && w.gl == 0)

@@ -267,6 +267,10 @@ typedef struct {
     int32_t tagged_pointers;            /* 1: the split layout ran its pointer phase on tagged scores */
     int32_t linear_gap;                 /* 1: the main launch ran the linear-gap pass (open == extend == mismatch) */
     int64_t seed_cells;                 /* DP cells executed by the seed launch */
+    int32_t raw_candidates;             /* candidates the run aligned from raw bytes because one of their two reads holds a byte
+                                           other than A/C/G/T (align.cpp:134), while the rest ran on the 2-bit image; 0 when no
+                                           set holds such a byte, or when the whole run compared raw bytes */
+    int32_t reserved;
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
 

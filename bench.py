@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use torch.distributed even at N=1")
     ap.add_argument("--no-others", action="store_true",
-                    help="skip the other single-GPU configurations (pacbio50mb, ont) that a default N=1 run appends under other_configs")
+                    help="skip what a default N=1 run appends: the other single-GPU configurations (pacbio50mb, ont; other_configs) "
+                         "and the headline workload off its fastest kernels (variants)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -318,6 +319,7 @@ def main():
             eng.close()
             eng = None
             out["other_configs"] = [side_config(w, args) for w in ("pacbio50mb", "ont")]
+            out["variants"] = [variant_config(v, args.workload, reads, my_cf, my_cr) for v in VARIANTS]
         print(json.dumps(out))
         sys.stdout.flush()
     if eng is not None:
@@ -394,16 +396,65 @@ def reference_baseline(reads, my_cf, rf, budget_s=8.0):
 def side_config(name, args):
     """One of the other single-GPU configurations (BASELINE.json configs[2], configs[4]): built exactly like the
     headline workload, 3 timed steps after 1 warm-up, parity gate against the oracle on a sample."""
-    import numpy as np
-    import oracle_py
-    from gact_amd import engine, workload
+    from gact_amd import workload
     blk = workload.make_block(name, candidates=args.candidates)
     cat, offs = blk.rs.concat()
     rcat, roffs = blk.rs.concat(rc=True)
-    eng = engine.Engine(n_slots=1)
+    return timed_config({"workload": name + "_self_overlap"}, cat, offs, rcat, roffs, blk.cf, blk.cr)
+
+
+# the headline workload again under the conditions that take it off its fastest kernels (each line says which kernels ran):
+# reads with N runs and soft-masked stretches (align.cpp:134 compares raw bytes: those candidates leave the 2-bit image),
+# the affine pass on the same linear scoring, a truly affine scoring, the int32 kernel
+VARIANTS = (
+    {"label": "1% of the reads hold an N run and a lower-case stretch", "dirty_fraction": 0.01},
+    {"label": "affine-gap pass forced on the linear scoring (GACT_HIP_NO_LIN=1)", "env": {"GACT_HIP_NO_LIN": "1"}},
+    {"label": "affine scoring match 2, mismatch -3, gap open -5, gap extend -2", "scoring": (2, -3, -5, -2)},
+    {"label": "int32 kernel forced (GACT_HIP_FORCE_INT32=1)", "env": {"GACT_HIP_FORCE_INT32": "1"}},
+)
+
+
+def variant_config(v, workload_name, reads, cf, cr):
+    import numpy as np
+    from gact_amd import synth
+    if v.get("dirty_fraction"):
+        rng = np.random.default_rng(20260903)
+        reads = list(reads)
+        picks = rng.choice(len(reads), max(1, int(round(len(reads) * v["dirty_fraction"]))), replace=False)
+        for k in picks:
+            r = reads[k].copy()
+            if len(r) > 600:
+                a = int(rng.integers(100, len(r) - 400))
+                r[a:a + 25] = ord("N")
+                b = int(rng.integers(100, len(r) - 400))
+                r[b:b + 60] = np.frombuffer(bytes(r[b:b + 60]).lower(), dtype=np.uint8)
+            reads[k] = r
+    offs = np.zeros(len(reads) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    cat = np.concatenate(reads)
+    rcat = np.concatenate([synth.revcomp(r) for r in reads])
+    saved = {k: os.environ.get(k) for k in v.get("env", {})}
+    os.environ.update(v.get("env", {}))
+    try:
+        return timed_config({"workload": workload_name + "_self_overlap", "variant": v["label"]}, cat, offs, rcat, offs, cf, cr,
+                            scoring=v.get("scoring", (1, -1, -1, -1)))
+    finally:
+        for k, old in saved.items():
+            if old is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old
+
+
+def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
+    import numpy as np
+    import oracle_py
+    from gact_amd import engine
+    eng = engine.Engine(n_slots=1, scoring=scoring)
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
-    nf, nr = len(blk.cf), len(blk.cr)
-    eng.candidates_upload(np.concatenate([blk.cf, blk.cr]))
+    nf, nr = len(cf), len(cr)
+    cands = np.concatenate([cf, cr])
+    eng.candidates_upload(cands)
     rec = np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE)
     eng.register_output(rec)
     steps, stats = 3, []
@@ -417,7 +468,9 @@ def side_config(name, args):
             stats.append(eng.last_run_stats())
     dt = (time.perf_counter() - t0) / steps
     cells = int(rec["cells"].sum())
-    # parity gate: a strided sample of both strands through the oracle, ~4 s of host time
+    st = stats[-1]
+    # parity gate: a strided sample of both strands through the oracle, ~4 s of host time; every candidate the engine
+    # aligned from raw bytes beside the 2-bit launches is in it when there are few
     orc = oracle_py.Oracle()
     threads = host_cores()
     fields = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
@@ -425,19 +478,22 @@ def side_config(name, args):
     stride = max(1, int(cells / target))
     checked = 0
     for comp, sl, qcat, qoffs in ((False, slice(0, nf), cat, offs), (True, slice(nf, nf + nr), rcat, roffs)):
-        c, got = np.concatenate([blk.cf, blk.cr])[sl][::stride], rec[sl][::stride]
-        want, _ = orc.gact_many(cat, offs, qcat, qoffs, c, complement=comp, same_file=True, n_threads=threads)
+        c, got = cands[sl][::stride], rec[sl][::stride]
+        want, _ = orc.gact_many(cat, offs, qcat, qoffs, c, complement=comp, same_file=True, scoring=scoring, n_threads=threads)
         if not all(np.array_equal(got[f], want[f]) for f in fields):
-            raise SystemExit("bench.py: PARITY FAILURE between the HIP engine and the oracle on workload %s" % name)
+            raise SystemExit("bench.py: PARITY FAILURE between the HIP engine and the oracle on %s" % head)
         checked += len(c)
-    st = stats[-1]
     eng.close()
-    return {"workload": name + "_self_overlap", "value": round(cells / dt / 1e9, 2), "unit": "GCUPS", "steps": steps, "warmup": 1,
-            "ms_per_step": round(dt * 1e3, 3), "candidates": int(nf + nr), "tiles": int(rec["n_tiles"].sum()), "cells_per_step": cells,
-            "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else ""),
-            "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
-            "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
-            "parity": {"checked_candidates": int(checked), "bit_exact": True}}
+    out = dict(head)
+    out.update({"value": round(cells / dt / 1e9, 2), "unit": "GCUPS", "steps": steps, "warmup": 1,
+                "ms_per_step": round(dt * 1e3, 3), "scoring": "%+d/%+d/%+d/%+d" % tuple(scoring), "candidates": int(nf + nr),
+                "raw_byte_candidates": int(st["raw_candidates"]),
+                "tiles": int(rec["n_tiles"].sum()), "cells_per_step": cells,
+                "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else ""),
+                "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
+                "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
+                "parity": {"checked_candidates": int(checked), "bit_exact": True}})
+    return out
 
 
 if __name__ == "__main__":

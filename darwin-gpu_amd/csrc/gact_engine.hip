@@ -121,6 +121,15 @@ struct Slot {
     DevBuf<gact::ChainState> chain_states;
     uint32_t *d_ws = nullptr;
     int *d_flags = nullptr;
+    // side lane: queues, workspace and stream of the raw-byte launches that run BESIDE the 2-bit launches of a routed
+    // run (launch_extend); made on first use
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_done = nullptr;
+    int *side_counter = nullptr;
+    DevBuf<int> side_live;
+    uint32_t *side_ws = nullptr;
+    int side_blocks = 0;                 // grid the side workspace is sized for
+    bool side_used = false;              // the last run had launches on it
     gact_overlap *h_records = nullptr;  // pinned staging for candidates_fetch (pageable D2H is staged by the runtime
     size_t h_records_cap = 0;           // in small chunks: 0.2-0.9 ms for 3.7 MB; pinned + memcpy: 0.25 ms)
     // a caller-owned output buffer page-locked on request (gact_hip_register_output): fetches whose destination lies
@@ -181,6 +190,7 @@ struct gact_hip_engine {
     bool lin = false;           // linear gaps (open == extend == mismatch): the drifted pass of gact_lin.hpp on 2-bit sets
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
+    bool side_lane = true;      // GACT_HIP_NO_SIDE_LANE unset: few raw-byte candidates run beside the 2-bit launches (launch_extend)
     bool route_other = true;    // GACT_HIP_NO_ROUTING unset: raw-byte kernels only for candidates with a non-ACGT read
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
     bool static_prio = false;   // GACT_HIP_STATIC_PRIO: fixed thresholds instead of the ranking (read once, at create)
@@ -221,14 +231,7 @@ int check_slot(gact_hip_engine *e, int slot)
 }
 
 // GACT_HIP_POISON_WS: seeded garbage over the slot's whole traceback workspace (poison_kernel)
-int poison_ws(gact_hip_engine *e, Slot &sl, uint32_t salt)
-{
-    if (!e->poison) return 0;
-    hipLaunchKernelGGL(gact::poison_kernel, dim3(e->prop.multiProcessorCount * 8), dim3(256), 0, sl.stream, sl.d_ws,
-                       e->ws_words_total + 64, e->poison * 0x01000193u + salt);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
+int poison_ws(gact_hip_engine *e, Slot &sl, uint32_t salt);
 
 // device buffers of a set for `total` bases in n_seqs sequences
 int reserve_set(SeqSet &s, int64_t total, int32_t n_seqs)
@@ -311,20 +314,75 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
 // [8+kBuckets..8+2*kBuckets) bucket_pop
 constexpr int kCounterInts = 8 + 2 * gact::kBuckets + gact::kEpochs;
 
-gact::ChainQueues queues(Slot &sl)
+// what a seed launch + main launch pair runs on: the slot's own stream, counters, hand-off lists and workspace, or
+// the slot's side lane.  Chain states and records are indexed by candidate and shared.
+struct Lane {
+    hipStream_t stream;
+    int *d_counter;
+    int *live;
+    size_t live_cap;
+    uint32_t *d_ws;
+    size_t ws_words;
+    int max_blocks;                      // 0: whatever the kernel's occupancy allows (the workspace is sized for it)
+};
+
+Lane main_lane(gact_hip_engine *e, Slot &sl) { return Lane{sl.stream, sl.d_counter, sl.live.p, sl.live.cap, sl.d_ws, e->ws_words_total, 0}; }
+
+gact::ChainQueues queues(const Lane &ln, Slot &sl)
 {
     gact::ChainQueues q;
-    q.pop_seed = sl.d_counter;
-    q.seed_cells = reinterpret_cast<unsigned long long *>(sl.d_counter + 2);
-    q.bucket_count = sl.d_counter + 8;
-    q.bucket_pop = sl.d_counter + 8 + gact::kBuckets;
-    q.live = sl.live.p;
-    q.live_stride = (int)(sl.live.cap / gact::kBuckets);
+    q.pop_seed = ln.d_counter;
+    q.seed_cells = reinterpret_cast<unsigned long long *>(ln.d_counter + 2);
+    q.bucket_count = ln.d_counter + 8;
+    q.bucket_pop = ln.d_counter + 8 + gact::kBuckets;
+    q.live = ln.live;
+    q.live_stride = (int)(ln.live_cap / gact::kBuckets);
     q.states = sl.chain_states.p;
-    q.longest_now = sl.d_counter + 8 + 2 * gact::kBuckets;
+    q.longest_now = ln.d_counter + 8 + 2 * gact::kBuckets;
     q.list_count = nullptr;
     q.list = nullptr;
     return q;
+}
+
+int poison_lane(gact_hip_engine *e, const Lane &ln, uint32_t salt)
+{
+    if (!e->poison) return 0;
+    hipLaunchKernelGGL(gact::poison_kernel, dim3(e->prop.multiProcessorCount * 8), dim3(256), 0, ln.stream, ln.d_ws,
+                       ln.ws_words + 64, e->poison * 0x01000193u + salt);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int poison_ws(gact_hip_engine *e, Slot &sl, uint32_t salt) { return poison_lane(e, main_lane(e, sl), salt); }
+
+size_t ws_words_for(const gact_hip_engine *e, int blocks)
+{
+    const size_t groups = (size_t)blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
+    return groups * gact::kSlots * (size_t)e->kp.ws_words;             // two tiles per group in the p16 kernel
+}
+
+// the side lane of a slot, for `count` candidates on at most `blocks` blocks
+int side_lane(gact_hip_engine *e, Slot &sl, int count, int blocks, Lane *out)
+{
+    if (!sl.side_stream) {
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        // ahead of the slot's own stream: its main launch must find room while the 2-bit seed launch drains
+        HIP_TRY(hipStreamCreateWithPriority(&sl.side_stream, hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreateWithFlags(&sl.side_done, hipEventDisableTiming));
+        HIP_TRY(hipMalloc((void **)&sl.side_counter, kCounterInts * sizeof(int)));
+    }
+    if (blocks > sl.side_blocks) {
+        if (sl.side_ws) (void)hipFree(sl.side_ws);
+        sl.side_ws = nullptr; sl.side_blocks = 0;
+        if (hipMalloc((void **)&sl.side_ws, (ws_words_for(e, blocks) + 64) * sizeof(uint32_t)) != hipSuccess)
+            return fail(GACT_HIP_ENOMEM, "side workspace allocation failed (%zu MiB)", ws_words_for(e, blocks) * 4 >> 20);
+        sl.side_blocks = blocks;
+        HIP_TRY(hipMemsetAsync(sl.side_ws, 0xA5, (ws_words_for(e, blocks) + 64) * sizeof(uint32_t), sl.side_stream));
+    }
+    if (sl.side_live.reserve((size_t)count * gact::kBuckets)) return fail(GACT_HIP_ENOMEM, "device allocation failed");
+    *out = Lane{sl.side_stream, sl.side_counter, sl.side_live.p, sl.side_live.cap, sl.side_ws, ws_words_for(e, sl.side_blocks), sl.side_blocks};
+    return 0;
 }
 
 // int32 kernel alone, or (scoring permitting) int32 seed launch for the first
@@ -354,58 +412,58 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     // one seed launch + (packed kernels) one main launch over `count` candidates at most
     // GACT_HIP_TRACE: every launch named on stderr and waited for (a faulting kernel is the last one named)
     static const bool trace = getenv("GACT_HIP_TRACE") != nullptr;
-    auto traced = [&](const char *what, int blocks, int count) -> int {
+    auto traced = [&](const Lane &ln, const char *what, int blocks, int count) -> int {
         if (!trace) return 0;
-        fprintf(stderr, "[gact_hip] %s: %d blocks, %d candidates (sets other %p %p %p, n %d %d %d, deferred list %p cap %zu) ... ", what, blocks, count,
-                (void *)rs.dev(false).other, (void *)qf.dev_or(false, rs).other, (void *)qr.dev_or(false, rs).other, rs.n, qf.n, qr.n,
-                (void *)sl.deferred.p, sl.deferred.cap);
+        fprintf(stderr, "[gact_hip] %s: %d blocks, %d candidates ... ", what, blocks, count);
         fflush(stderr);
-        HIP_TRY(hipStreamSynchronize(sl.stream));
+        HIP_TRY(hipStreamSynchronize(ln.stream));
         int dbg[8];
-        HIP_TRY(hipMemcpy(dbg, sl.d_counter, sizeof dbg, hipMemcpyDeviceToHost));
-        fprintf(stderr, "done (popped %d; routed %d to the 2-bit, %d to the raw-byte launches)\n", dbg[0], dbg[4], dbg[5]);
+        HIP_TRY(hipMemcpy(dbg, ln.d_counter, sizeof dbg, hipMemcpyDeviceToHost));
+        fprintf(stderr, "done (popped %d)\n", dbg[0]);
         return 0;
     };
-    auto run_pass = [&](bool raw, const int *list, const int *list_count, int count, bool first_pass) -> int {
+    auto run_pass = [&](const Lane &ln, bool raw, const int *list, const int *list_count, int count, bool first_pass) -> int {
+        auto grid = [&](int needed, int occupancy_cap) { return std::max(1, std::min(needed, ln.max_blocks ? std::min(occupancy_cap, ln.max_blocks) : occupancy_cap)); };
         const int groups_needed = e->p16 ? (count + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave)
                                          : (count + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
         const int seed_waves = (count + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
-        const int seed_blocks = std::max(1, std::min((seed_waves + 3) / 4, e->grid_blocks));
-        const int main_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->grid_blocks));
+        const int seed_blocks = grid((seed_waves + 3) / 4, e->grid_blocks);
+        const int main_blocks = grid((groups_needed + 3) / 4, e->grid_blocks);
         const gact::SeqSetDev d_rs = rs.dev(raw), d_qf = qf.dev_or(raw, rs), d_qr = qr.dev_or(raw, rs);
-        gact::ChainQueues cq = queues(sl);
+        gact::ChainQueues cq = queues(ln, sl);
         cq.list = list; cq.list_count = list_count;
         if (trace) {
-            fprintf(stderr, "[gact_hip] pass raw=%d listed=%d count=%d first=%d n=%d rc_from=%d\n", (int)raw, list != nullptr, count, first, n, rc_from);
-            fprintf(stderr, "[gact_hip]   ws %p + %zu MiB, counter %p, cands %p (%zu), overlaps %p, live %p (%zu), states %p (%zu x %zu B)\n", (void *)sl.d_ws,
-                    e->ws_words_total * 4 >> 20, (void *)sl.d_counter, (void *)sl.cands.p, sl.cands.cap, (void *)sl.overlaps.p, (void *)sl.live.p,
-                    sl.live.cap, (void *)sl.chain_states.p, sl.chain_states.cap, sizeof(gact::ChainState));
+            fprintf(stderr, "[gact_hip] pass raw=%d listed=%d side=%d count=%d first=%d n=%d rc_from=%d\n", (int)raw, list != nullptr,
+                    ln.stream != sl.stream, count, first, n, rc_from);
+            fprintf(stderr, "[gact_hip]   ws %p + %zu MiB, counter %p, cands %p (%zu), overlaps %p, live %p (%zu), states %p (%zu x %zu B)\n", (void *)ln.d_ws,
+                    ln.ws_words * 4 >> 20, (void *)ln.d_counter, (void *)sl.cands.p, sl.cands.cap, (void *)sl.overlaps.p, (void *)ln.live,
+                    ln.live_cap, (void *)sl.chain_states.p, sl.chain_states.cap, sizeof(gact::ChainState));
             fprintf(stderr, "[gact_hip]   ref raw %p packed %p offsets %p (%lld bases), query %p %p, rc %p %p\n", (void *)rs.d_raw, (void *)rs.d_packed,
                     (void *)rs.d_offsets, (long long)rs.total, (void *)qf.d_raw, (void *)qf.d_packed, (void *)qr.d_raw, (void *)qr.d_packed);
         }
         // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
         if (e->seed16) {
-            int blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_grid_blocks));
+            int blocks16 = grid((groups_needed + 3) / 4, e->seed_grid_blocks);
             auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
             if constexpr (C == 20) {                     // the linear-gap seed pass exists for the 20-column geometry only
                 if (!raw && e->lin) {
                     k16 = gact::seed_p16_kernel<C, false, true>;
-                    blocks16 = std::max(1, std::min((groups_needed + 3) / 4, e->seed_lin_grid_blocks));
+                    blocks16 = grid((groups_needed + 3) / 4, e->seed_lin_grid_blocks);
                 }
             }
-            hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, sl.stream,
+            hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, ln.stream,
                                kp, e->kc, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from,
-                               same_file, sl.overlaps.p, cq, sl.d_ws);
+                               same_file, sl.overlaps.p, cq, ln.d_ws);
         } else {
-            hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, sl.stream,
+            hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, ln.stream,
                                kp, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file,
-                               sl.overlaps.p, cq, e->p16 ? 1 : 0, sl.d_ws);
+                               sl.overlaps.p, cq, e->p16 ? 1 : 0, ln.d_ws);
         }
         HIP_TRY(hipGetLastError());
-        { int trc = traced(raw ? "seed launch (raw bytes)" : "seed launch (2-bit)", seed_blocks, count); if (trc) return trc; }
+        { int trc = traced(ln, raw ? "seed launch (raw bytes)" : "seed launch (2-bit)", seed_blocks, count); if (trc) return trc; }
         if (!e->p16) return 0;
-        if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, sl.stream));
-        { int prc = poison_ws(e, sl, 0x5bd1e995u); if (prc) return prc; }      // the main launch reads nothing the seed launch stored
+        if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, ln.stream));
+        { int prc = poison_lane(e, ln, 0x5bd1e995u); if (prc) return prc; }      // the main launch reads nothing the seed launch stored
         // fewer chains than the narrow layouts have tile slots: the launch lasts as long as its longest chain, so
         // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
         const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
@@ -431,15 +489,17 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // VALU idles): ONT-shape workload 150 ms -> 116 ms; one wave per SIMD: 132 ms
         const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : 2;
         const int wide_cap = std::min(lin ? e->wide_lin_grid_blocks : e->grid_blocks, per_cu * e->prop.multiProcessorCount);
-        const int wide_blocks = std::max(1, std::min((count + 15) / 16, wide_cap));             // 4 tiles per wave
-        const int lin_blocks = std::max(1, std::min((groups_needed + 3) / 4, e->lin_grid_blocks));
-        hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, sl.stream, kp,
-                           e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, sl.d_ws);
+        const int wide_blocks = grid((count + 15) / 16, wide_cap);             // 4 tiles per wave
+        const int lin_blocks = grid((groups_needed + 3) / 4, e->lin_grid_blocks);
+        hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, ln.stream, kp,
+                           e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws);
         HIP_TRY(hipGetLastError());
-        return traced(raw ? "main launch (raw bytes)" : "main launch (2-bit)", wide ? wide_blocks : (lin ? lin_blocks : main_blocks), count);
+        return traced(ln, raw ? "main launch (raw bytes)" : "main launch (2-bit)", wide ? wide_blocks : (lin ? lin_blocks : main_blocks), count);
     };
 
-    if (!mixed) return run_pass(any_other, nullptr, nullptr, n, true);
+    const Lane own = main_lane(e, sl);
+    sl.side_used = false;
+    if (!mixed) return run_pass(own, any_other, nullptr, nullptr, n, true);
     // the candidates sorted by what their two reads hold: two lists, their lengths back on the host (they decide grids
     // and layouts: the only host wait of a run, and only of a run over sets with such reads)
     const gact::SeqSetDev o_rs = rs.dev(false), o_qf = qf.dev_or(false, rs), o_qr = qr.dev_or(false, rs);
@@ -451,7 +511,26 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     HIP_TRY(hipStreamSynchronize(sl.stream));
     sl.routed_raw = routed[1];
     int rc = 0;
-    if (routed[0] > 0 && (rc = run_pass(false, sl.deferred.p, sl.d_counter + 4, routed[0], true))) return rc;
+    // Few raw-byte candidates beside many others: their launches last as long as their longest chain (a wave alone on
+    // its SIMD issues every ~8 cycles: a lone chain advances at a third of the machine's per-SIMD rate), so they run
+    // BESIDE the 2-bit launches, on the slot's side lane, started first -- the 2-bit main launch's last blocks become
+    // resident as the side lane's blocks leave.  Many of them (more than the side lane holds at one tile pair per
+    // group): one pass after the other on the whole machine.
+    const int side_cap = std::max(1, e->prop.multiProcessorCount / 2);
+    const int raw_blocks = ((routed[1] + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave) + 3) / 4;
+    if (routed[0] > 0 && routed[1] > 0 && e->side_lane && raw_blocks <= side_cap) {
+        Lane side;
+        if ((rc = side_lane(e, sl, routed[1], std::max(raw_blocks, std::min(side_cap, 16)), &side))) return rc;
+        HIP_TRY(hipMemsetAsync(side.d_counter, 0, kCounterInts * sizeof(int), side.stream));
+        if ((rc = poison_lane(e, side, 0x1b873593u))) return rc;
+        if ((rc = run_pass(side, true, sl.deferred.p + n, sl.d_counter + 5, routed[1], false))) return rc;
+        HIP_TRY(hipEventRecord(sl.side_done, side.stream));
+        sl.side_used = true;
+        if ((rc = run_pass(own, false, sl.deferred.p, sl.d_counter + 4, routed[0], true))) return rc;
+        HIP_TRY(hipStreamWaitEvent(sl.stream, sl.side_done, 0));
+        return 0;
+    }
+    if (routed[0] > 0 && (rc = run_pass(own, false, sl.deferred.p, sl.d_counter + 4, routed[0], true))) return rc;
     if (routed[1] == 0) return 0;
     if (routed[0] > 0) {
         // the queues again from empty (the seed launches' cell counter and the two lists stay)
@@ -459,7 +538,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         HIP_TRY(hipMemsetAsync(sl.d_counter + 8, 0, (kCounterInts - 8) * sizeof(int), sl.stream));
         { int prc = poison_ws(e, sl, 0x1b873593u); if (prc) return prc; }
     }
-    return run_pass(true, sl.deferred.p + n, sl.d_counter + 5, routed[1], routed[0] == 0);
+    return run_pass(own, true, sl.deferred.p + n, sl.d_counter + 5, routed[1], routed[0] == 0);
 }
 
 template <int C> int occupancy_blocks(int *out)
@@ -615,6 +694,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
+    e->side_lane = getenv("GACT_HIP_NO_SIDE_LANE") == nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
     if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
     if (const char *v = getenv("GACT_HIP_POISON_WS")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
@@ -647,10 +727,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         e->seed_lin_grid_blocks = std::min(sbl * e->prop.multiProcessorCount, e->grid_blocks);
     }
     e->lin_grid_blocks = e->grid_blocks;
-    auto ws_words_for = [&](int blocks) {
-        const size_t groups = (size_t)blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave;
-        return groups * gact::kSlots * (size_t)e->kp.ws_words;             // two tiles per group in the p16 kernel
-    };
+    auto ws_words_for = [&](int blocks) { return ::ws_words_for(e, blocks); };
     if (e->lin) {
         // the linear-gap split launch has its own occupancy, and its walker addresses the workspace with 32-bit byte
         // offsets (gact_device.hpp tb_refill_oct): engines that never run it are sized without it, and one whose
@@ -703,6 +780,12 @@ void gact_hip_destroy(gact_hip_engine *e)
         if (sl.d_counter) (void)hipFree(sl.d_counter);
         if (sl.d_flags) (void)hipFree(sl.d_flags);
         if (sl.d_ws) (void)hipFree(sl.d_ws);
+        if (sl.side_stream) (void)hipStreamSynchronize(sl.side_stream);
+        sl.side_live.release();
+        if (sl.side_counter) (void)hipFree(sl.side_counter);
+        if (sl.side_ws) (void)hipFree(sl.side_ws);
+        if (sl.side_done) (void)hipEventDestroy(sl.side_done);
+        if (sl.side_stream) (void)hipStreamDestroy(sl.side_stream);
         if (sl.h_records) (void)hipHostFree(sl.h_records);
         if (sl.reg_out) { (void)hipHostUnregister(sl.reg_out); (void)hipGetLastError(); }
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
@@ -1058,6 +1141,13 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
         st->handed_off = 0;
         for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b];
         memcpy(&st->seed_cells, &c[2], sizeof(int64_t));
+        if (sl.side_used) {                 // launches beside: their share of both figures
+            HIP_TRY(hipMemcpy(c, sl.side_counter, sizeof c, hipMemcpyDeviceToHost));
+            for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b];
+            int64_t sc = 0;
+            memcpy(&sc, &c[2], sizeof(int64_t));
+            st->seed_cells += sc;
+        }
     }
     return 0;
 }

@@ -13,7 +13,9 @@ FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitte
 MODES = {"auto": {"GACT_HIP_NO_WIDE": "1"}, "wide": {"GACT_HIP_FORCE_WIDE": "1"},
          "uniform": {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_UNIFORM": "1"},
          "affine": {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_LIN": "1"},
-         "int32-seed": {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_INT32_SEED": "1"}}
+         "int32-seed": {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_INT32_SEED": "1"},
+         # one pass after the other on the slot's own stream instead of the raw-byte launches beside the 2-bit ones
+         "one-after-the-other": {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_SIDE_LANE": "1"}}
 ALL_VARS = sorted({k for v in MODES.values() for k in v} | {"GACT_HIP_NO_ROUTING", "GACT_HIP_FORCE_INT32"})
 
 
@@ -76,7 +78,8 @@ def test_only_candidates_with_a_dirty_read_leave_the_two_bit_kernels(oracle, mon
         # (the uniform layout has no linear-gap pass; with every read dirty there is no 2-bit launch to report on)
         assert st["linear_gap"] == (linear and mode not in ("affine", "uniform") and touched < len(cands))
         assert st["layout"] == {"auto": "packed16-split", "wide": "packed16-wide", "uniform": "packed16-uniform",
-                                "affine": "packed16-split", "int32-seed": "packed16-split"}[mode]
+                                "affine": "packed16-split", "int32-seed": "packed16-split",
+                                "one-after-the-other": "packed16-split"}[mode]
 
 
 def test_routing_switched_off_and_int32(oracle, monkeypatch):

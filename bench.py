@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-others", action="store_true",
                     help="skip what a default N=1 run appends: the other single-GPU configurations (pacbio50mb, ont; other_configs) "
                          "and the headline workload off its fastest kernels (variants)")
+    ap.add_argument("--only-variants", action="store_true", help="of what a default N=1 run appends, the variants alone (profiling)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -318,7 +319,8 @@ def main():
             # the other single-GPU configurations of BASELINE.json, a few steps each, with their own parity gate
             eng.close()
             eng = None
-            out["other_configs"] = [side_config(w, args) for w in ("pacbio50mb", "ont")]
+            if not args.only_variants:
+                out["other_configs"] = [side_config(w, args) for w in ("pacbio50mb", "ont")]
             out["variants"] = [variant_config(v, args.workload, reads, my_cf, my_cr) for v in VARIANTS]
         print(json.dumps(out))
         sys.stdout.flush()

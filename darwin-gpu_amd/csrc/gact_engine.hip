@@ -22,6 +22,7 @@
 #include "gact_p16.hpp"
 #include "gact_p16s.hpp"
 #include "gact_lin.hpp"
+#include "gact_big.hpp"
 #include "dsoft_device.hpp"
 
 namespace {
@@ -184,6 +185,8 @@ struct gact_hip_engine {
     gact_hip_params params;
     gact::KParams kp;
     int C = 20;                 // columns per lane
+    int big_cb = 0;             // tile_size > 512: the one-wave-per-tile kernels of gact_big.hpp, 16 or 32 columns per lane
+    int big_blocks = 0;         //   and their grid (the workspace is one pointer matrix per wave)
     bool p16 = false;           // scoring fits the packed-int16 main kernel
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
     bool tagged = false;        // the packed main launch runs its pointer phase on tagged scores (any layout)
@@ -295,6 +298,17 @@ int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, c
     return 0;
 }
 
+// tile_size 513 .. 2048 (gact_big.hpp): one wave per tile / per candidate, raw bytes
+int launch_big_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &qf, const SeqSet &qr, int n, int states_stride)
+{
+    const int blocks = std::max(1, std::min((n + 3) / 4, e->big_blocks));
+    auto k = e->big_cb == 16 ? gact::big_tiles_kernel<16> : gact::big_tiles_kernel<32>;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream, e->kp, rs.dev(true), qf.dev_or(true, rs),
+                       qr.dev_or(true, rs), sl.tiles.p, n, sl.results.p, sl.states.p, states_stride, reinterpret_cast<uint8_t *>(sl.d_ws));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int C>
 int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &qf, const SeqSet &qr, int n,
                  int states_stride)
@@ -387,6 +401,21 @@ int side_lane(gact_hip_engine *e, Slot &sl, int count, int blocks, Lane *out)
 
 // int32 kernel alone, or (scoring permitting) int32 seed launch for the first
 // tiles followed by the packed-int16 main launch for the rest of every chain
+int launch_big_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, int same_file)
+{
+    const SeqSet &rs = e->sets[GACT_SET_REF];
+    const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
+    sl.two_phase = false; sl.routed_raw = 0; sl.side_used = false;
+    const Lane own = main_lane(e, sl);
+    const int blocks = std::max(1, std::min((n + 3) / 4, e->big_blocks));
+    auto k = e->big_cb == 16 ? gact::big_extend_kernel<16> : gact::big_extend_kernel<32>;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(gact::kBlockThreads), 0, sl.stream, e->kp, rs.dev(true), qf.dev_or(true, rs),
+                       qr.dev_or(true, rs), sl.cands.p, first, n, rc_from, same_file, sl.overlaps.p, queues(own, sl),
+                       reinterpret_cast<uint8_t *>(sl.d_ws));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int C>
 int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, int same_file)
 {
@@ -627,7 +656,8 @@ int run_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &qf, 
     HIP_TRY(hipMemsetAsync(sl.results.p, 0, (size_t)n * sizeof(gact_tile_result), sl.stream));
     { int prc = poison_ws(e, sl, 0x2545f491u); if (prc) return prc; }
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
-    int rc = (e->C == 20) ? launch_tiles<20>(e, sl, rs, qf, qr, n, states_stride)
+    int rc = e->big_cb ? launch_big_tiles(e, sl, rs, qf, qr, n, states_stride)
+           : (e->C == 20) ? launch_tiles<20>(e, sl, rs, qf, qr, n, states_stride)
                           : launch_tiles<32>(e, sl, rs, qf, qr, n, states_stride);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
@@ -677,13 +707,15 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         return fail(GACT_HIP_EDEVICE, "hipGetDeviceProperties failed");
     }
     e->C = (p->tile_size <= 20 * gact::kGroup) ? 20 : 32;
+    const bool big = p->tile_size > 32 * gact::kGroup;               // gact_big.hpp
+    if (big) e->big_cb = p->tile_size <= gact::BigGeom<16>::kTileMax ? 16 : 32;
     e->kp.tile_size = p->tile_size;
     e->kp.early = p->tile_size - p->tile_overlap;
     e->kp.match = p->match; e->kp.mismatch = p->mismatch;
     e->kp.open = p->gap_open; e->kp.ext = p->gap_extend;
     e->kp.thr = p->first_tile_score_threshold;
     e->kp.ws_words = (e->C == 20) ? gact::Geometry<20>::kWsWords : gact::Geometry<32>::kWsWords;
-    e->p16 = gact::p16_scoring_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
+    e->p16 = !big && gact::p16_scoring_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
              getenv("GACT_HIP_FORCE_INT32") == nullptr;
     e->split = e->p16 && e->C == 20 && e->kp.early <= gact::GeometrySplit<7, 13>::W2 &&
                getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
@@ -746,6 +778,12 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     }
     if (!e->lin) e->wide_lin_grid_blocks = e->grid_blocks;
     e->ws_words_total = ws_words_for(std::max(e->grid_blocks, std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
+    if (big) {
+        // one pointer matrix per wave (1 MB at 16 columns per lane, 4 MB at 32): at most 2 GiB per slot, two blocks per CU
+        const size_t per_block = (gact::kBlockThreads / 64) * (e->big_cb == 16 ? gact::BigGeom<16>::kWsBytes : gact::BigGeom<32>::kWsBytes);
+        e->big_blocks = (int)std::max<size_t>(1, std::min<size_t>(2 * (size_t)e->prop.multiProcessorCount, (2ull << 30) / per_block));
+        e->ws_words_total = (size_t)e->big_blocks * per_block / sizeof(uint32_t);
+    }
     e->slots.resize(p->n_slots);
     for (auto &sl : e->slots) {
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1005,7 +1043,8 @@ int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, i
     HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
     sl.two_phase = false;
     if (n > 0) {
-        rc = (e->C == 20) ? launch_extend<20>(e, sl, first, n, rc_from, same_file)
+        rc = e->big_cb ? launch_big_extend(e, sl, first, n, rc_from, same_file)
+           : (e->C == 20) ? launch_extend<20>(e, sl, first, n, rc_from, same_file)
                           : launch_extend<32>(e, sl, first, n, rc_from, same_file);
         if (rc) return rc;
     }

@@ -333,12 +333,25 @@ __global__ void route_kernel(const gact_candidate *__restrict__ cands, int first
                              const int32_t *__restrict__ qr_other, int *__restrict__ lists, int *__restrict__ counts)
 {
     const int stride = gridDim.x * blockDim.x;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        const int cand = first + k;
+    const int lane = threadIdx.x & 63;
+    for (int k0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63); k0 < n; k0 += stride) {      // (wave-uniform trip count)
+        const int k = k0 + lane;
+        const bool in = k < n;
+        const int cand = first + (in ? k : 0);
         const gact_candidate c = cands[cand];
         const int32_t *qo = cand >= rc_from ? qr_other : qf_other;
         const bool dirty = (ref_other && ref_other[c.ref_id]) || (qo && qo[c.query_id]);
-        lists[(dirty ? n : 0) + atomicAdd(&counts[dirty ? 1 : 0], 1)] = cand;
+        // one atomic per wave and list
+        const unsigned long long m1 = __ballot(in && dirty), m0 = __ballot(in && !dirty);
+        int b0 = 0, b1 = 0;
+        if (lane == 0) {
+            if (m0) b0 = atomicAdd(&counts[0], __popcll(m0));
+            if (m1) b1 = atomicAdd(&counts[1], __popcll(m1));
+        }
+        b0 = __shfl(b0, 0);
+        b1 = __shfl(b1, 0);
+        const unsigned long long below = (1ull << lane) - 1;
+        if (in) lists[dirty ? n + b1 + __popcll(m1 & below) : b0 + __popcll(m0 & below)] = cand;
     }
 }
 

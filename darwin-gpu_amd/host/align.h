@@ -19,7 +19,7 @@ enum states { Z, D, I, M };
 
 // Same arguments and the same returned queue as reference align.cpp:60-233:
 //   first  -> [max_score, max_i, max_j, states...],  !first -> [pos_score, states...]
-// Limit: ref_len, query_len <= 512 (the reference asserts < 2049, align.cpp:66).
+// ref_len, query_len < 2049 as in the reference (align.cpp:66); beyond 512 a slower kernel takes the tile (csrc/gact_big.hpp).
 std::queue<int> AlignWithBT(char *ref_seq, long long int ref_len,
                             char *query_seq, long long int query_len,
                             int match_score, int mismatch_score, int gap_open, int gap_extend,

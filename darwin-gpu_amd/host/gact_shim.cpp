@@ -230,13 +230,13 @@ std::queue<int> AlignWithBT(char *ref_seq, long long int ref_len, char *query_se
         ref_len = ref_pos; query_len = query_pos;
     }
     if (ref_len > GACT_HIP_MAX_TILE || query_len > GACT_HIP_MAX_TILE) {
-        printf("\nAlignWithBT: tile %lld x %lld is larger than the HIP engine's %d (the reference allows %d, "
-               "align.cpp:66-67; no caller uses more than tile_size)\n\n", ref_len, query_len, GACT_HIP_MAX_TILE,
-               MAX_TILE_SIZE - 1);
+        printf("\nAlignWithBT: tile %lld x %lld is larger than %d (the reference asserts the same, align.cpp:66-67)\n\n", ref_len,
+               query_len, GACT_HIP_MAX_TILE);
         exit(-1);
     }
     std::lock_guard<std::mutex> lk(g_side_mu);
-    const int tile = GACT_HIP_MAX_TILE;
+    // an engine per tile class: the register-tiled kernels up to GACT_HIP_FAST_TILE, the one-wave-per-tile kernels beyond
+    const int tile = (ref_len <= GACT_HIP_FAST_TILE && query_len <= GACT_HIP_FAST_TILE) ? GACT_HIP_FAST_TILE : GACT_HIP_MAX_TILE;
     int early = early_terminate < 1 ? 1 : (early_terminate > tile ? tile : early_terminate);
     gact_hip_engine *e = side_engine(tile, tile - early, match_score, mismatch_score, gap_open, gap_extend, 1);
     const int32_t rl = (int32_t)ref_len, ql = (int32_t)query_len;

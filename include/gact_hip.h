@@ -35,11 +35,12 @@ extern "C" {
 #define GACT_HIP_ENOMEM     -3
 #define GACT_HIP_ERANGE     -4   /* descriptor points outside a sequence   */
 
-/* Largest tile_size the kernels are built for.  BOUNDARY LIMIT: the reference's CPU AlignWithBT asserts
- * ref_len, query_len < 2049 (align.h:19, align.cpp:66-67) and its CUDA kernel stops at 324 (cuda_header.h:45);
- * every caller in the reference passes tile_size = 320 (params.cfg:22).  gact_hip_create refuses larger
- * values, and the align.h shim refuses tiles beyond it with a message (gact_shim.cpp::AlignWithBT). */
-#define GACT_HIP_MAX_TILE   512
+/* Largest tile_size: the reference's CPU AlignWithBT asserts ref_len, query_len < 2049 (align.h:19, align.cpp:66-67); its
+ * CUDA kernel stops at 324 (cuda_header.h:45), and every caller in the reference passes tile_size = 320 (params.cfg:22).
+ * Up to GACT_HIP_FAST_TILE the register-tiled kernels run (packed int16 where the scoring allows); beyond it, one wave
+ * per tile with the pointer matrix in HBM (csrc/gact_big.hpp): the whole interface, at a fraction of the speed. */
+#define GACT_HIP_FAST_TILE  512
+#define GACT_HIP_MAX_TILE   2048
 
 /* traceback states, align.h:23 */
 #define GACT_STATE_Z 0

@@ -10,7 +10,7 @@ n=0
 for p in "${PS[@]}"; do
   n=$((n+1))
   rm -rf $OUT/pass$n
-  (cd $R && env $ENVV timeout -k 10 300 rocprofv3 --pmc $p --output-format csv -d $OUT/pass$n -- $CMD > $OUT/pass$n.log 2> $OUT/pass$n.err) || echo "pass $n failed: $(tail -n 3 $OUT/pass$n.err)"
+  (cd $R && env $ENVV timeout -k 10 ${PASS_TIMEOUT:-300} rocprofv3 --pmc $p --output-format csv -d $OUT/pass$n -- $CMD > $OUT/pass$n.log 2> $OUT/pass$n.err) || echo "pass $n failed: $(tail -n 3 $OUT/pass$n.err)"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys

@@ -226,3 +226,70 @@ def test_config4_one_rank_of_eight(oracle, capsys):
     with open(os.path.join(out_dir, "config4_one_rank_of_eight.jsonl"), "w") as f:
         for ln in lines:
             f.write(json.dumps(ln) + "\n")
+
+
+def test_config2_eight_feeder_slots(capsys):
+    """BASELINE config 2 as the reference runs it: 8 feeder threads, each with its own GPU_storage (darwin.cpp:619-629)
+    = its own engine slot (stream, queues, 1.3 GB of traceback workspace), all launching at once on one device.  The
+    candidates of ecoli10x dealt round-robin over 8 slots from 8 host threads: the same records as one slot, and the
+    aggregate rate (8 persistent grids share the CUs) recorded next to the one-slot rate."""
+    import json
+    import threading
+    from gact_amd import engine, workload
+    blk = workload.make_block("ecoli10x", candidates="dsoft")
+    cat, offs = blk.rs.concat(); rcat, roffs = blk.rs.concat(rc=True)
+    rows = []
+    want = None
+    for n_slots in (1, 8):
+        eng = engine.Engine(n_slots=n_slots)
+        eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+        parts = []
+        for k in range(n_slots):
+            cf, cr = blk.cf[k::n_slots], blk.cr[k::n_slots]
+            eng.candidates_upload(np.concatenate([cf, cr]), slot=k)
+            parts.append((len(cf), len(cr), np.zeros(len(cf) + len(cr), dtype=engine.OVERLAP_DTYPE)))
+        steps = 4
+        errors = []
+
+        def feeder(k):
+            try:
+                nf, nr, rec = parts[k]
+                for _ in range(steps):
+                    eng.candidates_run_mixed(nf + nr, rc_from=nf, slot=k)
+                    eng.candidates_fetch(nf + nr, slot=k, out=rec)
+            except Exception as err:                      # surfaced below: a thread's exception is not pytest's
+                errors.append(err)
+
+        for k in range(n_slots):                          # warm-up, one slot at a time
+            nf, nr, rec = parts[k]
+            eng.candidates_run_mixed(nf + nr, rc_from=nf, slot=k)
+            eng.candidates_fetch(nf + nr, slot=k, out=rec)
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=feeder, args=(k,)) for k in range(n_slots)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        dt = (time.perf_counter() - t0) / steps
+        assert not errors, errors
+        # back into list order
+        rec_f = np.zeros(len(blk.cf), dtype=engine.OVERLAP_DTYPE); rec_r = np.zeros(len(blk.cr), dtype=engine.OVERLAP_DTYPE)
+        for k, (nf, nr, rec) in enumerate(parts):
+            rec_f[k::n_slots] = rec[:nf]; rec_r[k::n_slots] = rec[nf:]
+        rec = np.concatenate([rec_f, rec_r])
+        cells = int(rec["cells"].sum())
+        if want is None:
+            want = rec.copy()
+        else:
+            assert rec.tobytes() == want.tobytes()
+        rows.append({"slots": n_slots, "feeder_threads": n_slots, "ms_per_step": round(dt * 1e3, 2), "gcups": round(cells / dt / 1e9, 1),
+                     "workspace_gb": round(n_slots * 1.29, 1)})
+        eng.close()
+    line = json.dumps({"config": "2 (ecoli10x), feeder threads", "candidates": int(len(blk.cf) + len(blk.cr)), "rows": rows, "records_equal": True})
+    with capsys.disabled():
+        print("\nFEEDERS " + line)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "config2_feeder_slots.json"), "w") as f:
+        f.write(line + "\n")
+    assert rows[1]["gcups"] > 0.5 * rows[0]["gcups"]

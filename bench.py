@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--no-others", action="store_true",
                     help="skip what a default N=1 run appends: the other single-GPU configurations (pacbio50mb, ont; other_configs) "
                          "and the headline workload off its fastest kernels (variants)")
+    ap.add_argument("--slots", type=int, default=4,
+                    help="engine slots the timed steps alternate over (steps in flight at once: the fetch of step k is taken after "
+                         "step k+S-1 has been launched).  1: every step is launched, waited for and fetched before the next")
     ap.add_argument("--only-variants", action="store_true", help="of what a default N=1 run appends, the variants alone (profiling)")
     args = ap.parse_args()
 
@@ -145,17 +148,22 @@ def main():
     rcat = np.concatenate([synth.revcomp(r) for r in reads])
     t_gen = time.time() - t_gen
 
-    eng = engine.Engine(device_id=local_rank, n_slots=1)
+    global SIDE_SLOTS
+    S = SIDE_SLOTS = max(1, args.slots)
+    eng = engine.Engine(device_id=local_rank, n_slots=S)
     info = eng.device_info()
     eng.upload(engine.SET_REF, cat, offs)
     eng.upload(engine.SET_QUERY, cat, offs)
     eng.upload(engine.SET_QUERY_RC, rcat, offs)
-    # forward-strand candidates first, reverse-complement ones after (one launch walks both)
+    # forward-strand candidates first, reverse-complement ones after (one launch walks both); the same list in every
+    # slot: a step is one pass over it, on whichever slot is its turn
     nf, nr = len(my_cf), len(my_cr)
-    eng.candidates_upload(np.concatenate([my_cf, my_cr]), slot=0)
+    for k in range(S):
+        eng.candidates_upload(np.concatenate([my_cf, my_cr]), slot=k)
 
     def barrier():
-        eng.sync(0)
+        for k in range(S):
+            eng.sync(k)
         if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
@@ -163,9 +171,11 @@ def main():
 
     kernel_ms = []
 
-    rec_buf = np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE)      # the job's output buffer, owned by the caller
+    # the job's output buffers, owned by the caller, page-locked once, explicitly: fetches are one DMA
+    rec_bufs = [np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE) for _ in range(S)]
     if nf + nr:
-        eng.register_output(rec_buf, slot=0)                     # page-locked once, explicitly: fetches are one DMA
+        for k in range(S):
+            eng.register_output(rec_bufs[k], slot=k)
 
     gather = None
     if use_dist:
@@ -173,38 +183,63 @@ def main():
         # the engine's device-resident record array (no host round trip in front of RCCL)
         # (32 bytes per record travel: the eight numbers of an output line; dist.LINE_DTYPE)
         gather = gdist.RecordGather(torch, dist, nf + nr, gdist.LINE_BYTES, rank, world, "cuda")
-        dev_rec = gdist.DeviceRecords(eng.device_overlaps_ptr(0), nf + nr, engine.OVERLAP_DTYPE.itemsize)
+        dev_recs = [gdist.DeviceRecords(eng.device_overlaps_ptr(k), nf + nr, engine.OVERLAP_DTYPE.itemsize) for k in range(S)]
 
-    def step(record_ms=False):
-        eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=0)
+    def launch(slot):
+        eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=slot)
+
+    def complete(slot, record_ms=False):
+        """the output of the step that ran on `slot`, where it is due: records on the host (rank 0's host for N > 1)"""
         gathered = None
         if use_dist:
-            eng.sync(0)                                  # the engine's own stream: records complete in HBM
-            parts = gather(dev_rec)
+            eng.sync(slot)                               # the engine's own stream: records complete in HBM
+            parts = gather(dev_recs[slot])
             if rank == 0:
                 gathered = gather.to_host(parts, gdist.LINE_DTYPE)          # the job's output, on the host
             rec = None
         else:
-            rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
+            rec = eng.candidates_fetch(nf + nr, slot=slot, out=rec_bufs[slot])
         if record_ms:
-            kernel_ms.append(eng.last_run_stats(0))
+            kernel_ms.append(eng.last_run_stats(slot))
         return rec, gathered
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n_steps, in_flight, record_ms=False):
+        """n_steps passes over the candidate list, `in_flight` of them launched before the oldest is completed"""
+        rec = gathered = None
+        for k in range(n_steps):
+            launch(k % in_flight)
+            if k >= in_flight - 1:
+                rec, gathered = complete((k - (in_flight - 1)) % in_flight, record_ms)
+        for k in range(max(n_steps - (in_flight - 1), 0), n_steps):
+            rec, gathered = complete(k % in_flight, record_ms)
+        return rec, gathered
+
+    run_steps(args.warmup, S)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rec, gathered = step(record_ms=True)
+    rec, gathered = run_steps(args.steps, S, record_ms=(S == 1))
     barrier()
     dt = time.perf_counter() - t0
+    # the same steps one at a time (launched, waited for, fetched), for the per-kernel HIP-event times of the roofline
+    # and as the figure of rounds 1-2: inside the timed region kernels of consecutive steps share the machine and a
+    # kernel's own duration says nothing about it
+    n_single, dt_single = args.steps, dt / max(args.steps, 1)
+    if S > 1:
+        n_single = min(5, max(2, args.steps))
+        t1 = time.perf_counter()
+        run_steps(n_single, 1, record_ms=True)
+        barrier()
+        dt_single = (time.perf_counter() - t1) / n_single
     if rec is None:          # distributed run: the engine's full records of this rank, for the cell count and the parity gate
-        rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_buf)
+        rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_bufs[0])
         # what rank 0 gathered of EVERY rank is what that rank's engine holds (checksums, one all_gather)
         try:
             gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
         except RuntimeError as err:
             raise SystemExit("bench.py: %s" % err)
+    for k in range(1, S):    # every slot holds the same records
+        if eng.candidates_fetch(nf + nr, slot=k).tobytes() != eng.candidates_fetch(nf + nr, slot=0).tobytes():
+            raise SystemExit("bench.py: slot %d's records differ from slot 0's" % k)
     rf, rr = rec[:nf], rec[nf:]
 
     my_cells = int(rf["cells"].sum() + rr["cells"].sum())
@@ -281,6 +316,9 @@ def main():
             "executed": executed,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": main_kernel,
+            "measured_in": ("the timed region" if S == 1 else
+                            "%d steps run one at a time right after the timed region: inside it the kernels of %d steps in flight share "
+                            "the machine, and a kernel's own HIP-event duration is not what the chip spent on it" % (n_single, S)),
             "kernel_ms": round(float(k_ms), 3),
             "kernel_cells": main_cells, "seed_kernel": {"packed16": "seed_p16_kernel<20>", "int32": "extend_kernel<20>"}[kernel_ms[-1]["seed_layout"]],
             "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
@@ -306,8 +344,15 @@ def main():
                        "scoring": "+1/-1/-1/-1", "reads": len(reads), "bases": int(offs[-1]),
                        "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles,
                        "cells_per_step": tot_cells, "parallelism": "candidates dealt round-robin over %d GPU(s)" % world,
+                       # steps in flight: step k's records are fetched after step k+S-1 has been launched, each step on an engine
+                       # slot of its own (stream, queues, workspace) -- what the reference's 8 feeder threads with a GPU_storage
+                       # each do (darwin.cpp:619-629); every step is complete, records on the host, inside the timed region
+                       "slots_in_flight": S,
                        "arch": info["arch"], "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,
+            # the same pass one step at a time (launch, wait, fetch, then the next): the figure of rounds 1 and 2
+            "single_slot": {"value": round(my_cells * (world if use_dist else 1) / dt_single / 1e9, 2) if not use_dist else None,
+                            "ms_per_step": round(dt_single * 1e3, 3), "steps": n_single},
         }
         if gathered is not None:
             out["config"]["gathered_records"] = int(sum(len(g) for g in gathered))
@@ -408,6 +453,9 @@ def side_config(name, args):
 # the headline workload again under the conditions that take it off its fastest kernels (each line says which kernels ran):
 # reads with N runs and soft-masked stretches (align.cpp:134 compares raw bytes: those candidates leave the 2-bit image),
 # the affine pass on the same linear scoring, a truly affine scoring, the int32 kernel
+SIDE_SLOTS = 4          # steps in flight in other_configs / variants (set from --slots)
+
+
 VARIANTS = (
     {"label": "1% of the reads hold an N run and a lower-case stretch", "dirty_fraction": 0.01},
     {"label": "affine-gap pass forced on the linear scoring (GACT_HIP_NO_LIN=1)", "env": {"GACT_HIP_NO_LIN": "1"}},
@@ -452,13 +500,18 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
     import numpy as np
     import oracle_py
     from gact_amd import engine
-    eng = engine.Engine(n_slots=1, scoring=scoring)
+    S = SIDE_SLOTS
+    eng = engine.Engine(n_slots=S, scoring=scoring)
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
     nf, nr = len(cf), len(cr)
     cands = np.concatenate([cf, cr])
-    eng.candidates_upload(cands)
-    rec = np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE)
-    eng.register_output(rec)
+    recs = []
+    for k in range(S):
+        eng.candidates_upload(cands, slot=k)
+        recs.append(np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE))
+        eng.register_output(recs[k], slot=k)
+    rec = recs[0]
+    # one step at a time on slot 0 (1 warm-up + 3 timed): the kernels' own times
     steps, stats = 3, []
     for k in range(1 + steps):
         if k == 1:
@@ -468,7 +521,25 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
         eng.candidates_fetch(nf + nr, out=rec)
         if k:
             stats.append(eng.last_run_stats())
-    dt = (time.perf_counter() - t0) / steps
+    dt_single = (time.perf_counter() - t0) / steps
+    # S steps in flight, like the headline (S untimed, 2 S timed)
+    dt = dt_single
+    if S > 1:
+        def run_steps(n):
+            for k in range(n):
+                eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=k % S)
+                if k >= S - 1:
+                    eng.candidates_fetch(nf + nr, slot=(k - (S - 1)) % S, out=recs[(k - (S - 1)) % S])
+            for k in range(max(n - (S - 1), 0), n):
+                eng.candidates_fetch(nf + nr, slot=k % S, out=recs[k % S])
+        run_steps(S)
+        t0 = time.perf_counter()
+        run_steps(2 * S)
+        dt = (time.perf_counter() - t0) / (2 * S)
+        for k in range(1, S):
+            if recs[k].tobytes() != rec.tobytes():
+                raise SystemExit("bench.py: slot %d's records differ from slot 0's on %s" % (k, head))
+        steps = 2 * S
     cells = int(rec["cells"].sum())
     st = stats[-1]
     # parity gate: a strided sample of both strands through the oracle, ~4 s of host time; every candidate the engine
@@ -487,8 +558,9 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
         checked += len(c)
     eng.close()
     out = dict(head)
-    out.update({"value": round(cells / dt / 1e9, 2), "unit": "GCUPS", "steps": steps, "warmup": 1,
-                "ms_per_step": round(dt * 1e3, 3), "scoring": "%+d/%+d/%+d/%+d" % tuple(scoring), "candidates": int(nf + nr),
+    out.update({"value": round(cells / dt / 1e9, 2), "unit": "GCUPS", "steps": steps, "warmup": S if S > 1 else 1,
+                "ms_per_step": round(dt * 1e3, 3), "slots_in_flight": S,
+                "single_slot": {"value": round(cells / dt_single / 1e9, 2), "ms_per_step": round(dt_single * 1e3, 3), "steps": 3}, "scoring": "%+d/%+d/%+d/%+d" % tuple(scoring), "candidates": int(nf + nr),
                 "raw_byte_candidates": int(st["raw_candidates"]),
                 "tiles": int(rec["n_tiles"].sum()), "cells_per_step": cells,
                 "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else ""),

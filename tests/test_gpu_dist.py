@@ -28,14 +28,15 @@ def _env():
     return env
 
 
-def test_bench_force_dist_as_a_child_process():
+@pytest.mark.parametrize("slots,steps", [(4, 6), (4, 2), (1, 2)], ids=["four-in-flight", "fewer-steps-than-slots", "one-at-a-time"])
+def test_bench_force_dist_as_a_child_process(slots, steps):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--workload", "ecoli10x_small",
-                          "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"], capture_output=True, text=True,
-                         cwd=ROOT, env=_env(), timeout=600)
+                          "--steps", str(steps), "--warmup", "1", "--cpu-seconds", "2", "--slots", str(slots)], capture_output=True,
+                         text=True, cwd=ROOT, env=_env(), timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 1 and res["value"] > 0
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["steps"] == steps and res["config"]["slots_in_flight"] == slots
     assert res["config"]["gathered_records"] == res["config"]["candidates"] > 2000
     assert res["parity"]["bit_exact"] is True and res["parity"]["checked_candidates"] > 100
 

@@ -527,6 +527,7 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
     dt_single = (time.perf_counter() - t0) / steps
     # S steps in flight, like the headline (S untimed, 2 S timed)
     dt = dt_single
+    flight = stats[-1]
     if S > 1:
         def run_steps(n):
             for k in range(n):
@@ -543,6 +544,7 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
             if recs[k].tobytes() != rec.tobytes():
                 raise SystemExit("bench.py: slot %d's records differ from slot 0's on %s" % (k, head))
         steps = 2 * S
+        flight = eng.last_run_stats(S - 1)
     cells = int(rec["cells"].sum())
     st = stats[-1]
     # parity gate: a strided sample of both strands through the oracle, ~4 s of host time; every candidate the engine
@@ -566,7 +568,9 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
                 "single_slot": {"value": round(cells / dt_single / 1e9, 2), "ms_per_step": round(dt_single * 1e3, 3), "steps": 3}, "scoring": "%+d/%+d/%+d/%+d" % tuple(scoring), "candidates": int(nf + nr),
                 "raw_byte_candidates": int(st["raw_candidates"]),
                 "tiles": int(rec["n_tiles"].sum()), "cells_per_step": cells,
-                "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else ""),
+                # (a launch made while another slot is running takes the layout with the better throughput)
+                "kernel_layout": flight["layout"] + ("-lin" if flight["linear_gap"] else ""),
+                "single_slot_kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else ""),
                 "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
                 "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
                 "parity": {"checked_candidates": int(checked), "bit_exact": True}})

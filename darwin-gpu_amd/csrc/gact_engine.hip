@@ -193,6 +193,7 @@ struct gact_hip_engine {
     bool lin = false;           // linear gaps (open == extend == mismatch): the drifted pass of gact_lin.hpp on 2-bit sets
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
+    bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
     bool side_lane = true;      // GACT_HIP_NO_SIDE_LANE unset: few raw-byte candidates run beside the 2-bit launches (launch_extend)
     bool route_other = true;    // GACT_HIP_NO_ROUTING unset: raw-byte kernels only for candidates with a non-ACGT read
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
@@ -437,6 +438,14 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     kp.prio_bases[1] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : rank16;
     sl.two_phase = e->p16;
     sl.routed_raw = 0;
+    // Is another slot of this engine still running?  Then this launch shares the machine (feeder threads, steps in
+    // flight) and what counts is throughput: the wide layout -- faster per chain, slower per cell, made for a launch
+    // that has the CUs to itself and lasts as long as its longest chain -- is not taken on its own account.
+    bool shared_machine = false;
+    if (e->shared_hint)
+        for (const Slot &other : e->slots)
+            if (&other != &sl && other.timed && other.ev1 && hipEventQuery(other.ev1) == hipErrorNotReady) { shared_machine = true; break; }
+    (void)hipGetLastError();                 // (hipErrorNotReady is an answer, not a failure)
 
     // one seed launch + (packed kernels) one main launch over `count` candidates at most
     // GACT_HIP_TRACE: every launch named on stderr and waited for (a faulting kernel is the last one named)
@@ -496,7 +505,8 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // fewer chains than the narrow layouts have tile slots: the launch lasts as long as its longest chain, so
         // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
         const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
-        const bool wide = C == 20 && e->wide >= 0 && (e->wide > 0 || count <= narrow_slots);
+        // (the side lane's few chains are latency-bound whatever else runs)
+        const bool wide = C == 20 && e->wide >= 0 && (e->wide > 0 || (count <= narrow_slots && (!shared_machine || ln.stream != sl.stream)));
         using gact::extend_p16_kernel;
         const bool tg = e->tagged;
         const bool lin = e->lin && !raw && (wide || e->split);
@@ -727,6 +737,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
     e->side_lane = getenv("GACT_HIP_NO_SIDE_LANE") == nullptr;
+    e->shared_hint = getenv("GACT_HIP_NO_SHARED_HINT") == nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
     if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
     if (const char *v = getenv("GACT_HIP_POISON_WS")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;

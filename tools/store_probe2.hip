@@ -43,6 +43,21 @@ template <int MODE> __global__ __launch_bounds__(256, 3) void probe(int iters, i
             p[192] = make_uint4(w[12], w[13], w[14], w[15]);
             if (MODE & 2) p += 256; else if ((it & 31) == 31) p -= 0;
             if ((MODE & 2) && (it & 31) == 31) p -= 32 * 256;
+            // the registers the stores read, written again right behind them (what a kernel short of registers does
+            // with its temporaries): by a vector instruction (16), by an LDS read's return (32)
+            if (MODE & 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(w[k]) : "v"(x));
+            }
+            if (MODE & 32) {
+#pragma unroll
+                for (int k = 0; k < 16; k += 4) asm volatile("ds_read_b32 %0, %1" : "+v"(w[k]) : "v"((uint32_t)(lane * 4)) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (MODE & 48) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) x ^= w[k] & 0x10000u;
+            }
         }
         if (MODE & 4) {                                 // the same bytes through LDS writes
             uint4 *q = reinterpret_cast<uint4 *>(lds) + (threadIdx.x >> 6) * 256 + lane;
@@ -98,6 +113,9 @@ int main()
         run(probe<4>, "4 x ds_write_b128", vb, ws, first);
         run(probe<8>, "nothing in the flush; an LDS read waited for per 32 instructions", vb, ws, first);
         run(probe<11>, "stores advancing + the LDS reads", vb, ws, first);
+        run(probe<3 + 16>, "stores advancing, their data registers rewritten by v_add_u32 right behind them", vb, ws, first);
+        run(probe<3 + 32>, "stores advancing, four of their data registers rewritten by ds_read_b32 right behind them", vb, ws, first);
+        run(probe<11 + 16>, "stores advancing + the LDS reads + data registers rewritten by v_add_u32", vb, ws, first);
     }
     printf("\n ]}\n");
     return 0;

@@ -1,6 +1,9 @@
 """Randomised parity sweep: random tile geometry, thresholds, scorings, read sets with and without N, candidate
 lists with false and edge hits -- every record field against the oracle, in whichever kernels the engine picks
-plus the forced variants.  python tools/stress_parity.py [n_configs] [seed]"""
+plus the forced variants.  python tools/stress_parity.py [n_configs] [seed]
+STRESS_RAW_ONLY=1: every read set with N / lower case (the raw-byte kernels only).  STRESS_MIXED=1: a quarter of the reads
+dirty (per-candidate routing, side lane), tiles beyond 512 now and then (gact_big.hpp), and both strands launched on two
+slots at once (runs in flight, the layout hint)."""
 import os
 import sys
 import time
@@ -13,6 +16,7 @@ from gact_amd import engine, synth
 
 n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 RAW_ONLY = os.environ.get("STRESS_RAW_ONLY")      # every read set with N (and lower case): the raw-byte kernels only
+MIXED = os.environ.get("STRESS_MIXED")
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 orc = oracle_py.Oracle()
 FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
@@ -29,6 +33,10 @@ for it in range(n_cfg):
     overlap = int(rng.integers(0, max(1, tile - 16)))
     if rng.random() < 0.4:                       # the reference's geometry class: split layout, tagged pointers
         tile, overlap = 320, int(rng.integers(112, 300))
+    big = bool(MIXED) and rng.random() < 0.15
+    if big:
+        tile = int(rng.choice([513, 600, 1024, 1500, 2048]))
+        overlap = int(rng.integers(0, tile // 2))
     thr = int(rng.integers(1, 70))
     match = int(rng.integers(1, 7))
     scoring = (match, -int(rng.integers(0, 8)), -int(rng.integers(0, 12)), -int(rng.integers(0, 6)))
@@ -36,12 +44,23 @@ for it in range(n_cfg):
         g = -int(rng.choice([0, 1, 1, 1, 2, 3, 5, 9]))
         scoring = (match, g, g, g)
     n_frac = float(rng.choice([0.0, 0.0, 0.004])) if RAW_ONLY is None else 0.004
+    if MIXED:
+        n_frac = 0.0
     rs = synth.simulate_reads(int(rng.integers(6000, 20000)), n_reads=int(rng.integers(6, 16)), seed=int(rng.integers(1 << 30)),
                               mean_len=int(rng.integers(1500, 5000)), sd_len=900, min_len=200, max_len=9000, n_frac=n_frac)
     if n_frac > 0 and rng.random() < 0.5:       # soft-masked stretches: lower case compares unequal to upper (align.cpp:134)
         for r in rs.reads:
             a = int(rng.integers(0, max(1, len(r) - 40)))
             r[a:a + 30] = np.frombuffer(bytes(r[a:a + 30]).lower(), dtype=np.uint8)
+    if MIXED:                                    # a few dirty reads among clean ones
+        for k in range(rs.n):
+            if rng.random() < 0.25 and len(rs.reads[k]) > 120:
+                r = rs.reads[k]
+                a = int(rng.integers(0, len(r) - 60))
+                r[a:a + int(rng.integers(1, 30))] = ord("N")
+                if rng.random() < 0.5:
+                    b = int(rng.integers(0, len(r) - 60))
+                    r[b:b + 40] = np.frombuffer(bytes(r[b:b + 40]).lower(), dtype=np.uint8)
     cf, cr = synth.synth_candidates(rs, seed=int(rng.integers(1 << 30)), min_overlap=150,
                                     false_frac=float(rng.choice([0.0, 0.3])))
     cat, offs = rs.concat()
@@ -51,20 +70,33 @@ for it in range(n_cfg):
         if len(cands):
             want[comp], _ = orc.gact_many(cat, offs, qcat, qoffs, cands, complement=comp, same_file=True, tile_size=tile,
                                           tile_overlap=overlap, threshold=thr, scoring=scoring, n_threads=16)
-    for mode in MODES:
+    for mode in (MODES[:1] if big else MODES):
         for k in ALL:
             os.environ.pop(k, None)
         os.environ.update(mode)
-        eng = engine.Engine(tile_size=tile, tile_overlap=overlap, scoring=scoring, threshold=thr)
+        eng = engine.Engine(tile_size=tile, tile_overlap=overlap, scoring=scoring, threshold=thr, n_slots=2)
         eng.upload(engine.SET_REF, cat, offs)
         eng.upload(engine.SET_QUERY, cat, offs)
         eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+        in_flight = {}
+        if MIXED:                                # both strands launched before either is fetched, a slot each
+            for slot, (comp, cands) in enumerate(((False, cf), (True, cr))):
+                if len(cands):
+                    eng.candidates_upload(cands, slot=slot)
+                    eng.candidates_run(len(cands), complement=comp, same_file=True, slot=slot)
+            for slot, (comp, cands) in enumerate(((False, cf), (True, cr))):
+                if len(cands):
+                    in_flight[comp] = (eng.candidates_fetch(len(cands), slot=slot).copy(), eng.last_run_stats(slot))
         for comp, cands in ((False, cf), (True, cr)):
             if not len(cands):
                 continue
-            got = eng.extend(cands, complement=comp, same_file=True)
-            st = eng.last_run_stats()
-            key = st["layout"] + ("-lin" if st["linear_gap"] else "") + "/" + st["seed_layout"]
+            if MIXED:
+                got, st = in_flight[comp]
+            else:
+                got = eng.extend(cands, complement=comp, same_file=True)
+                st = eng.last_run_stats()
+            key = ("big" if big else st["layout"] + ("-lin" if st["linear_gap"] else "") + "/" + st["seed_layout"]) + (
+                "+routed" if st["raw_candidates"] else "")
             layouts[key] = layouts.get(key, 0) + 1
             for f in FIELDS:
                 if not np.array_equal(got[f], want[comp][f]):

@@ -117,6 +117,22 @@ __device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *
         wb[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x07060302u)) : 0u;
     }
     if (!store) return;          // a lane whose columns no walk can reach (uniform layout, non-first tiles)
+#if GACT_EXP_SPLIT_FLUSH
+    // timing experiment (wrong results): `mid` misused as a selector -- (void *)1: tile A's words only, (void *)2: tile B's
+    if (mid == (unsigned long long *)1 || mid == (unsigned long long *)2) {
+        const bool a_only = mid == (unsigned long long *)1;
+        uint32_t x = 0;
+#pragma unroll
+        for (int n = 0; n < QD * 4; n++) x ^= a_only ? wb[n] : wa[n];
+        asm volatile("" :: "v"(x));
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            if (a_only) qA[q * kWsRow] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
+            else qB[q * kWsRow] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+        }
+        return;
+    }
+#endif
 #ifdef GACT_STAMPS_FLUSH
     {
         uint32_t x = 0;
@@ -331,6 +347,25 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     unsigned long long fl_clk = 0, fl_n = 0, fl_st = 0;
 #endif
     while (t + 7 <= T_end) {
+#if GACT_EXP_SPLIT_FLUSH
+        // timing experiment (wrong results): two flush events of half the bytes per eight steps
+        for (int s8 = 0; s8 < 4; s8++, t++) step_tagged(t);
+        lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, exp_store, (unsigned long long *)2);
+        for (int s8 = 0; s8 < 4; s8++, t++) step_tagged(t);
+        lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, exp_store, (unsigned long long *)1);
+        k += 8;
+        qA += QD * kWsRow;
+        qB += QD * kWsRow;
+        continue;
+#elif GACT_EXP_FLUSH16
+        // timing experiment (wrong results): every other flush left out -- half the events, half the bytes
+        for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
+        k += 8;
+        if (k & 8) { flush([](uint32_t w) { return w; }); }
+        qA += QD * kWsRow;
+        qB += QD * kWsRow;
+        continue;
+#endif
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
 #ifdef GACT_STAMPS_FLUSH

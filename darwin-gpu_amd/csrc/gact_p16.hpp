@@ -54,6 +54,12 @@ __device__ unsigned long long g_wave_cycles[4096];
 #ifndef GACT_PTR_BUFFER_STORE
 #define GACT_PTR_BUFFER_STORE 0
 #endif
+#ifndef GACT_EXP_SPLIT_FLUSH
+#define GACT_EXP_SPLIT_FLUSH 0
+#endif
+#ifndef GACT_EXP_FLUSH16
+#define GACT_EXP_FLUSH16 0
+#endif
 #ifndef GACT_EXP_STORE_ONE
 #define GACT_EXP_STORE_ONE 0
 #endif

@@ -92,7 +92,7 @@ def floor_slots_per_cell(linear, tile, early):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ecoli10x")
     ap.add_argument("--candidates", default="dsoft", choices=["dsoft", "synthetic"],

@@ -89,6 +89,41 @@ def floor_slots_per_cell(linear, tile, early):
                                               "pointer_window_fraction": round(window, 4)}
 
 
+def main_kernel_name(st):
+    """the main launch's kernel as rocprofv3 names it (template arguments without spaces), from gact_hip_run_stats"""
+    name = {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
+            "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>",
+            "packed16-wide": "extend_p16_kernel<WideLayout>"}[st["layout"]]
+    if st.get("linear_gap"):            # linear gap scoring: the drifted pass (gact_lin.hpp)
+        name = {"extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayoutLin<7,13>>",
+                "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutLin>"}[name]
+    elif st["tagged_pointers"]:         # pointer phase on tagged scores: the layouts' TAG variants
+        name = {"extend_p16_kernel<UniformLayout<20>>": "extend_p16_kernel<UniformLayout<20,16,true>>",
+                "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
+                "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutTagged>"}[name]
+    return name
+
+
+def short_roofline(st, k_ms, main_cells, info, workload_name, tile, early):
+    """roofline of a side configuration's main launch, the headline's figures in short"""
+    kernel = main_kernel_name(st)
+    linear = bool(st.get("linear_gap"))
+    floor, _ = floor_slots_per_cell(linear, tile, early)
+    peak = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
+    achieved = floor * main_cells / (k_ms * 1e-3) / 1e12
+    out = {"bound": "valu", "kernel": kernel, "kernel_ms": round(k_ms, 3), "kernel_cells": int(main_cells),
+           "floor_slots_per_cell": round(floor, 3), "achieved": round(achieved, 3), "peak": round(peak, 3),
+           "unit": "T lane-op slots/s", "frac": round(achieved / peak, 4),
+           "valu_issue_utilisation": None, "executed_slots_per_cell": None, "traffic": None, "source": None}
+    pmc = pmc_lookup(workload_name, "dsoft", kernel, main_cells)
+    if pmc:
+        out["executed_slots_per_cell"] = round(pmc["insts_valu"] * 64.0 / main_cells, 3)
+        out["valu_issue_utilisation"] = round(pmc["insts_valu"] * float(ISSUE_CYCLES) / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0), 4)
+        out["traffic"] = int((pmc["write_kib"] + FETCH_SIZE_CORRECTION * pmc["fetch_kib"]) * 1024)
+        out["source"] = pmc["source"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,16 +303,7 @@ def main():
         seed_cells = int(kernel_ms[-1]["seed_cells"])
         main_cells = my_cells - seed_cells
         achieved_tops = OPS_PER_CELL * main_cells / (k_ms * 1e-3) / 1e12
-        main_kernel = {"int32": "extend_kernel", "packed16-uniform": "extend_p16_kernel<UniformLayout<20>>",
-                       "packed16-split": "extend_p16_kernel<SplitLayout<7,13>>",
-                       "packed16-wide": "extend_p16_kernel<WideLayout>"}[kernel_ms[-1]["layout"]]
-        if kernel_ms[-1].get("linear_gap"):            # linear gap scoring: the drifted pass (gact_lin.hpp)
-            main_kernel = {"extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayoutLin<7,13>>",
-                           "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutLin>"}[main_kernel]
-        elif kernel_ms[-1]["tagged_pointers"]:         # pointer phase on tagged scores: the layouts' TAG variants
-            main_kernel = {"extend_p16_kernel<UniformLayout<20>>": "extend_p16_kernel<UniformLayout<20,16,true>>",
-                           "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
-                           "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutTagged>"}[main_kernel]
+        main_kernel = main_kernel_name(kernel_ms[-1])
         measured_rate = eng.measure_valu_rate()
         # issue peak: one wave64 VALU instruction per SIMD per 2 cycles = 128 lane-op slots per CU per clock
         peak_slots = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
@@ -505,6 +531,7 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
     from gact_amd import engine
     S = SIDE_SLOTS
     eng = engine.Engine(n_slots=S, scoring=scoring)
+    info, eng_tile, eng_overlap = eng.device_info(), eng.tile_size, eng.tile_overlap
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
     nf, nr = len(cf), len(cr)
     cands = np.concatenate([cf, cr])
@@ -574,6 +601,10 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
                 "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
                 "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
                 "parity": {"checked_candidates": int(checked), "bit_exact": True}})
+    if st["packed16"] and head.get("variant") is None:
+        # the main launch of the one-at-a-time leg against the issue peak (counters: the committed PMC pass of this workload)
+        out["roofline"] = short_roofline(st, float(np.mean([x["main_ms"] for x in stats])), cells - int(st["seed_cells"]), info,
+                                         head["workload"].replace("_self_overlap", ""), eng_tile, eng_tile - eng_overlap)
     return out
 
 

@@ -778,6 +778,9 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         int lb = 0;
         if ((rc = lin_occupancy_blocks(&lb))) { delete e; return rc; }
         e->lin_grid_blocks = std::max(e->grid_blocks, lb * e->prop.multiProcessorCount);
+        // GACT_HIP_LIN_BLOCKS=<n>: a smaller persistent grid for the split linear-gap launch (measurements: fewer resident
+        // tiles = a smaller live pointer footprint)
+        if (const char *v = getenv("GACT_HIP_LIN_BLOCKS")) e->lin_grid_blocks = std::max(1, std::min(atoi(v), e->lin_grid_blocks));
         int wb = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wb, gact::extend_p16_kernel<gact::WideLayoutLin, false>,
                                                              gact::kBlockThreads, 0));

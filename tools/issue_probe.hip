@@ -39,6 +39,17 @@
         if ((threadIdx.x & 63) == 0) cycles[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;  \
     }
 
+// register banks (VGPR number mod 4): the same instruction with every source in one bank and in different banks
+PROBE(p_bank_max3_same, if (k == 0) asm volatile("v_pk_maximum3_f16 v40, v20, v24, v28\n\tv_pk_maximum3_f16 v41, v20, v24, v28\n\tv_pk_maximum3_f16 v42, v20, v24, v28\n\tv_pk_maximum3_f16 v43, v20, v24, v28\n\tv_pk_maximum3_f16 v44, v20, v24, v28\n\tv_pk_maximum3_f16 v45, v20, v24, v28\n\tv_pk_maximum3_f16 v46, v20, v24, v28\n\tv_pk_maximum3_f16 v47, v20, v24, v28\n\tv_pk_maximum3_f16 v48, v20, v24, v28\n\tv_pk_maximum3_f16 v49, v20, v24, v28\n\tv_pk_maximum3_f16 v50, v20, v24, v28\n\tv_pk_maximum3_f16 v51, v20, v24, v28\n\tv_pk_maximum3_f16 v52, v20, v24, v28\n\tv_pk_maximum3_f16 v53, v20, v24, v28\n\tv_pk_maximum3_f16 v54, v20, v24, v28\n\tv_pk_maximum3_f16 v55, v20, v24, v28" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_pk_maximum3_f16 v40, v20, v24, v28\n\tv_pk_maximum3_f16 v41, v20, v24, v28\n\tv_pk_maximum3_f16 v42, v20, v24, v28\n\tv_pk_maximum3_f16 v43, v20, v24, v28\n\tv_pk_maximum3_f16 v44, v20, v24, v28\n\tv_pk_maximum3_f16 v45, v20, v24, v28\n\tv_pk_maximum3_f16 v46, v20, v24, v28\n\tv_pk_maximum3_f16 v47, v20, v24, v28\n\tv_pk_maximum3_f16 v48, v20, v24, v28\n\tv_pk_maximum3_f16 v49, v20, v24, v28\n\tv_pk_maximum3_f16 v50, v20, v24, v28\n\tv_pk_maximum3_f16 v51, v20, v24, v28\n\tv_pk_maximum3_f16 v52, v20, v24, v28\n\tv_pk_maximum3_f16 v53, v20, v24, v28\n\tv_pk_maximum3_f16 v54, v20, v24, v28\n\tv_pk_maximum3_f16 v55, v20, v24, v28" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_max3_diff, if (k == 0) asm volatile("v_pk_maximum3_f16 v40, v20, v21, v22\n\tv_pk_maximum3_f16 v41, v20, v21, v22\n\tv_pk_maximum3_f16 v42, v20, v21, v22\n\tv_pk_maximum3_f16 v43, v20, v21, v22\n\tv_pk_maximum3_f16 v44, v20, v21, v22\n\tv_pk_maximum3_f16 v45, v20, v21, v22\n\tv_pk_maximum3_f16 v46, v20, v21, v22\n\tv_pk_maximum3_f16 v47, v20, v21, v22\n\tv_pk_maximum3_f16 v48, v20, v21, v22\n\tv_pk_maximum3_f16 v49, v20, v21, v22\n\tv_pk_maximum3_f16 v50, v20, v21, v22\n\tv_pk_maximum3_f16 v51, v20, v21, v22\n\tv_pk_maximum3_f16 v52, v20, v21, v22\n\tv_pk_maximum3_f16 v53, v20, v21, v22\n\tv_pk_maximum3_f16 v54, v20, v21, v22\n\tv_pk_maximum3_f16 v55, v20, v21, v22" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_pk_maximum3_f16 v40, v20, v21, v22\n\tv_pk_maximum3_f16 v41, v20, v21, v22\n\tv_pk_maximum3_f16 v42, v20, v21, v22\n\tv_pk_maximum3_f16 v43, v20, v21, v22\n\tv_pk_maximum3_f16 v44, v20, v21, v22\n\tv_pk_maximum3_f16 v45, v20, v21, v22\n\tv_pk_maximum3_f16 v46, v20, v21, v22\n\tv_pk_maximum3_f16 v47, v20, v21, v22\n\tv_pk_maximum3_f16 v48, v20, v21, v22\n\tv_pk_maximum3_f16 v49, v20, v21, v22\n\tv_pk_maximum3_f16 v50, v20, v21, v22\n\tv_pk_maximum3_f16 v51, v20, v21, v22\n\tv_pk_maximum3_f16 v52, v20, v21, v22\n\tv_pk_maximum3_f16 v53, v20, v21, v22\n\tv_pk_maximum3_f16 v54, v20, v21, v22\n\tv_pk_maximum3_f16 v55, v20, v21, v22" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_pkmax_same, if (k == 0) asm volatile("v_pk_max_i16 v40, v20, v24\n\tv_pk_max_i16 v41, v20, v24\n\tv_pk_max_i16 v42, v20, v24\n\tv_pk_max_i16 v43, v20, v24\n\tv_pk_max_i16 v44, v20, v24\n\tv_pk_max_i16 v45, v20, v24\n\tv_pk_max_i16 v46, v20, v24\n\tv_pk_max_i16 v47, v20, v24\n\tv_pk_max_i16 v48, v20, v24\n\tv_pk_max_i16 v49, v20, v24\n\tv_pk_max_i16 v50, v20, v24\n\tv_pk_max_i16 v51, v20, v24\n\tv_pk_max_i16 v52, v20, v24\n\tv_pk_max_i16 v53, v20, v24\n\tv_pk_max_i16 v54, v20, v24\n\tv_pk_max_i16 v55, v20, v24" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_pk_max_i16 v40, v20, v24\n\tv_pk_max_i16 v41, v20, v24\n\tv_pk_max_i16 v42, v20, v24\n\tv_pk_max_i16 v43, v20, v24\n\tv_pk_max_i16 v44, v20, v24\n\tv_pk_max_i16 v45, v20, v24\n\tv_pk_max_i16 v46, v20, v24\n\tv_pk_max_i16 v47, v20, v24\n\tv_pk_max_i16 v48, v20, v24\n\tv_pk_max_i16 v49, v20, v24\n\tv_pk_max_i16 v50, v20, v24\n\tv_pk_max_i16 v51, v20, v24\n\tv_pk_max_i16 v52, v20, v24\n\tv_pk_max_i16 v53, v20, v24\n\tv_pk_max_i16 v54, v20, v24\n\tv_pk_max_i16 v55, v20, v24" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_pkmax_diff, if (k == 0) asm volatile("v_pk_max_i16 v40, v20, v21\n\tv_pk_max_i16 v41, v20, v21\n\tv_pk_max_i16 v42, v20, v21\n\tv_pk_max_i16 v43, v20, v21\n\tv_pk_max_i16 v44, v20, v21\n\tv_pk_max_i16 v45, v20, v21\n\tv_pk_max_i16 v46, v20, v21\n\tv_pk_max_i16 v47, v20, v21\n\tv_pk_max_i16 v48, v20, v21\n\tv_pk_max_i16 v49, v20, v21\n\tv_pk_max_i16 v50, v20, v21\n\tv_pk_max_i16 v51, v20, v21\n\tv_pk_max_i16 v52, v20, v21\n\tv_pk_max_i16 v53, v20, v21\n\tv_pk_max_i16 v54, v20, v21\n\tv_pk_max_i16 v55, v20, v21" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_pk_max_i16 v40, v20, v21\n\tv_pk_max_i16 v41, v20, v21\n\tv_pk_max_i16 v42, v20, v21\n\tv_pk_max_i16 v43, v20, v21\n\tv_pk_max_i16 v44, v20, v21\n\tv_pk_max_i16 v45, v20, v21\n\tv_pk_max_i16 v46, v20, v21\n\tv_pk_max_i16 v47, v20, v21\n\tv_pk_max_i16 v48, v20, v21\n\tv_pk_max_i16 v49, v20, v21\n\tv_pk_max_i16 v50, v20, v21\n\tv_pk_max_i16 v51, v20, v21\n\tv_pk_max_i16 v52, v20, v21\n\tv_pk_max_i16 v53, v20, v21\n\tv_pk_max_i16 v54, v20, v21\n\tv_pk_max_i16 v55, v20, v21" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_perm_same, if (k == 0) asm volatile("v_perm_b32 v40, v20, v24, v28\n\tv_perm_b32 v41, v20, v24, v28\n\tv_perm_b32 v42, v20, v24, v28\n\tv_perm_b32 v43, v20, v24, v28\n\tv_perm_b32 v44, v20, v24, v28\n\tv_perm_b32 v45, v20, v24, v28\n\tv_perm_b32 v46, v20, v24, v28\n\tv_perm_b32 v47, v20, v24, v28\n\tv_perm_b32 v48, v20, v24, v28\n\tv_perm_b32 v49, v20, v24, v28\n\tv_perm_b32 v50, v20, v24, v28\n\tv_perm_b32 v51, v20, v24, v28\n\tv_perm_b32 v52, v20, v24, v28\n\tv_perm_b32 v53, v20, v24, v28\n\tv_perm_b32 v54, v20, v24, v28\n\tv_perm_b32 v55, v20, v24, v28" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_perm_b32 v40, v20, v24, v28\n\tv_perm_b32 v41, v20, v24, v28\n\tv_perm_b32 v42, v20, v24, v28\n\tv_perm_b32 v43, v20, v24, v28\n\tv_perm_b32 v44, v20, v24, v28\n\tv_perm_b32 v45, v20, v24, v28\n\tv_perm_b32 v46, v20, v24, v28\n\tv_perm_b32 v47, v20, v24, v28\n\tv_perm_b32 v48, v20, v24, v28\n\tv_perm_b32 v49, v20, v24, v28\n\tv_perm_b32 v50, v20, v24, v28\n\tv_perm_b32 v51, v20, v24, v28\n\tv_perm_b32 v52, v20, v24, v28\n\tv_perm_b32 v53, v20, v24, v28\n\tv_perm_b32 v54, v20, v24, v28\n\tv_perm_b32 v55, v20, v24, v28" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_perm_diff, if (k == 0) asm volatile("v_perm_b32 v40, v20, v21, v22\n\tv_perm_b32 v41, v20, v21, v22\n\tv_perm_b32 v42, v20, v21, v22\n\tv_perm_b32 v43, v20, v21, v22\n\tv_perm_b32 v44, v20, v21, v22\n\tv_perm_b32 v45, v20, v21, v22\n\tv_perm_b32 v46, v20, v21, v22\n\tv_perm_b32 v47, v20, v21, v22\n\tv_perm_b32 v48, v20, v21, v22\n\tv_perm_b32 v49, v20, v21, v22\n\tv_perm_b32 v50, v20, v21, v22\n\tv_perm_b32 v51, v20, v21, v22\n\tv_perm_b32 v52, v20, v21, v22\n\tv_perm_b32 v53, v20, v21, v22\n\tv_perm_b32 v54, v20, v21, v22\n\tv_perm_b32 v55, v20, v21, v22" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_perm_b32 v40, v20, v21, v22\n\tv_perm_b32 v41, v20, v21, v22\n\tv_perm_b32 v42, v20, v21, v22\n\tv_perm_b32 v43, v20, v21, v22\n\tv_perm_b32 v44, v20, v21, v22\n\tv_perm_b32 v45, v20, v21, v22\n\tv_perm_b32 v46, v20, v21, v22\n\tv_perm_b32 v47, v20, v21, v22\n\tv_perm_b32 v48, v20, v21, v22\n\tv_perm_b32 v49, v20, v21, v22\n\tv_perm_b32 v50, v20, v21, v22\n\tv_perm_b32 v51, v20, v21, v22\n\tv_perm_b32 v52, v20, v21, v22\n\tv_perm_b32 v53, v20, v21, v22\n\tv_perm_b32 v54, v20, v21, v22\n\tv_perm_b32 v55, v20, v21, v22" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_add_same, if (k == 0) asm volatile("v_add_u32 v40, v20, v24\n\tv_add_u32 v41, v20, v24\n\tv_add_u32 v42, v20, v24\n\tv_add_u32 v43, v20, v24\n\tv_add_u32 v44, v20, v24\n\tv_add_u32 v45, v20, v24\n\tv_add_u32 v46, v20, v24\n\tv_add_u32 v47, v20, v24\n\tv_add_u32 v48, v20, v24\n\tv_add_u32 v49, v20, v24\n\tv_add_u32 v50, v20, v24\n\tv_add_u32 v51, v20, v24\n\tv_add_u32 v52, v20, v24\n\tv_add_u32 v53, v20, v24\n\tv_add_u32 v54, v20, v24\n\tv_add_u32 v55, v20, v24" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_add_u32 v40, v20, v24\n\tv_add_u32 v41, v20, v24\n\tv_add_u32 v42, v20, v24\n\tv_add_u32 v43, v20, v24\n\tv_add_u32 v44, v20, v24\n\tv_add_u32 v45, v20, v24\n\tv_add_u32 v46, v20, v24\n\tv_add_u32 v47, v20, v24\n\tv_add_u32 v48, v20, v24\n\tv_add_u32 v49, v20, v24\n\tv_add_u32 v50, v20, v24\n\tv_add_u32 v51, v20, v24\n\tv_add_u32 v52, v20, v24\n\tv_add_u32 v53, v20, v24\n\tv_add_u32 v54, v20, v24\n\tv_add_u32 v55, v20, v24" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_add_diff, if (k == 0) asm volatile("v_add_u32 v40, v20, v21\n\tv_add_u32 v41, v20, v21\n\tv_add_u32 v42, v20, v21\n\tv_add_u32 v43, v20, v21\n\tv_add_u32 v44, v20, v21\n\tv_add_u32 v45, v20, v21\n\tv_add_u32 v46, v20, v21\n\tv_add_u32 v47, v20, v21\n\tv_add_u32 v48, v20, v21\n\tv_add_u32 v49, v20, v21\n\tv_add_u32 v50, v20, v21\n\tv_add_u32 v51, v20, v21\n\tv_add_u32 v52, v20, v21\n\tv_add_u32 v53, v20, v21\n\tv_add_u32 v54, v20, v21\n\tv_add_u32 v55, v20, v21" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_add_u32 v40, v20, v21\n\tv_add_u32 v41, v20, v21\n\tv_add_u32 v42, v20, v21\n\tv_add_u32 v43, v20, v21\n\tv_add_u32 v44, v20, v21\n\tv_add_u32 v45, v20, v21\n\tv_add_u32 v46, v20, v21\n\tv_add_u32 v47, v20, v21\n\tv_add_u32 v48, v20, v21\n\tv_add_u32 v49, v20, v21\n\tv_add_u32 v50, v20, v21\n\tv_add_u32 v51, v20, v21\n\tv_add_u32 v52, v20, v21\n\tv_add_u32 v53, v20, v21\n\tv_add_u32 v54, v20, v21\n\tv_add_u32 v55, v20, v21" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_pkmad_same, if (k == 0) asm volatile("v_pk_mad_u16 v40, v20, v24, v28\n\tv_pk_mad_u16 v41, v20, v24, v28\n\tv_pk_mad_u16 v42, v20, v24, v28\n\tv_pk_mad_u16 v43, v20, v24, v28\n\tv_pk_mad_u16 v44, v20, v24, v28\n\tv_pk_mad_u16 v45, v20, v24, v28\n\tv_pk_mad_u16 v46, v20, v24, v28\n\tv_pk_mad_u16 v47, v20, v24, v28\n\tv_pk_mad_u16 v48, v20, v24, v28\n\tv_pk_mad_u16 v49, v20, v24, v28\n\tv_pk_mad_u16 v50, v20, v24, v28\n\tv_pk_mad_u16 v51, v20, v24, v28\n\tv_pk_mad_u16 v52, v20, v24, v28\n\tv_pk_mad_u16 v53, v20, v24, v28\n\tv_pk_mad_u16 v54, v20, v24, v28\n\tv_pk_mad_u16 v55, v20, v24, v28" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_pk_mad_u16 v40, v20, v24, v28\n\tv_pk_mad_u16 v41, v20, v24, v28\n\tv_pk_mad_u16 v42, v20, v24, v28\n\tv_pk_mad_u16 v43, v20, v24, v28\n\tv_pk_mad_u16 v44, v20, v24, v28\n\tv_pk_mad_u16 v45, v20, v24, v28\n\tv_pk_mad_u16 v46, v20, v24, v28\n\tv_pk_mad_u16 v47, v20, v24, v28\n\tv_pk_mad_u16 v48, v20, v24, v28\n\tv_pk_mad_u16 v49, v20, v24, v28\n\tv_pk_mad_u16 v50, v20, v24, v28\n\tv_pk_mad_u16 v51, v20, v24, v28\n\tv_pk_mad_u16 v52, v20, v24, v28\n\tv_pk_mad_u16 v53, v20, v24, v28\n\tv_pk_mad_u16 v54, v20, v24, v28\n\tv_pk_mad_u16 v55, v20, v24, v28" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
+PROBE(p_bank_pkmad_diff, if (k == 0) asm volatile("v_pk_mad_u16 v40, v20, v21, v22\n\tv_pk_mad_u16 v41, v20, v21, v22\n\tv_pk_mad_u16 v42, v20, v21, v22\n\tv_pk_mad_u16 v43, v20, v21, v22\n\tv_pk_mad_u16 v44, v20, v21, v22\n\tv_pk_mad_u16 v45, v20, v21, v22\n\tv_pk_mad_u16 v46, v20, v21, v22\n\tv_pk_mad_u16 v47, v20, v21, v22\n\tv_pk_mad_u16 v48, v20, v21, v22\n\tv_pk_mad_u16 v49, v20, v21, v22\n\tv_pk_mad_u16 v50, v20, v21, v22\n\tv_pk_mad_u16 v51, v20, v21, v22\n\tv_pk_mad_u16 v52, v20, v21, v22\n\tv_pk_mad_u16 v53, v20, v21, v22\n\tv_pk_mad_u16 v54, v20, v21, v22\n\tv_pk_mad_u16 v55, v20, v21, v22" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");, if (k == 0) asm volatile("v_pk_mad_u16 v40, v20, v21, v22\n\tv_pk_mad_u16 v41, v20, v21, v22\n\tv_pk_mad_u16 v42, v20, v21, v22\n\tv_pk_mad_u16 v43, v20, v21, v22\n\tv_pk_mad_u16 v44, v20, v21, v22\n\tv_pk_mad_u16 v45, v20, v21, v22\n\tv_pk_mad_u16 v46, v20, v21, v22\n\tv_pk_mad_u16 v47, v20, v21, v22\n\tv_pk_mad_u16 v48, v20, v21, v22\n\tv_pk_mad_u16 v49, v20, v21, v22\n\tv_pk_mad_u16 v50, v20, v21, v22\n\tv_pk_mad_u16 v51, v20, v21, v22\n\tv_pk_mad_u16 v52, v20, v21, v22\n\tv_pk_mad_u16 v53, v20, v21, v22\n\tv_pk_mad_u16 v54, v20, v21, v22\n\tv_pk_mad_u16 v55, v20, v21, v22" ::: "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");)
 // independent: accumulator k only; dependent: accumulator 0 again and again
 PROBE(p_add_u32, asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[k]) : "v"(x));, asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[0]) : "v"(x));)
 PROBE(p_max_i32, asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[k]) : "v"(x));, asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[0]) : "v"(x));)
@@ -156,6 +167,16 @@ int main(int argc, char **argv)
     printf(" \"note\": \"cycles[w] = [shader clocks between two issues of one wave, the same divided by w = the SIMD's issue "
            "interval], w = resident waves per SIMD; s_memtime inside the wave, median over all waves\",\n \"rows\": [\n");
     bool first = true;
+    ROW("v_pk_maximum3_f16, sources v20, v24, v28 (one VGPR bank)", p_bank_max3_same, 16)
+    ROW("v_pk_maximum3_f16, sources v20, v21, v22 (three banks)", p_bank_max3_diff, 16)
+    ROW("v_pk_max_i16, sources v20, v24 (one VGPR bank)", p_bank_pkmax_same, 16)
+    ROW("v_pk_max_i16, sources v20, v21 (two banks)", p_bank_pkmax_diff, 16)
+    ROW("v_perm_b32, sources v20, v24, v28 (one VGPR bank)", p_bank_perm_same, 16)
+    ROW("v_perm_b32, sources v20, v21, v22 (three banks)", p_bank_perm_diff, 16)
+    ROW("v_add_u32, sources v20, v24 (one VGPR bank)", p_bank_add_same, 16)
+    ROW("v_add_u32, sources v20, v21 (two banks)", p_bank_add_diff, 16)
+    ROW("v_pk_mad_u16, sources v20, v24, v28 (one VGPR bank)", p_bank_pkmad_same, 16)
+    ROW("v_pk_mad_u16, sources v20, v21, v22 (three banks)", p_bank_pkmad_diff, 16)
     ROW("v_pk_maximum3_f16", p_pk_maximum3_f16, 1)
     ROW("v_pk_max_f16", p_pk_max_f16, 1)
     ROW("v_pk_max_u16", p_pk_max_u16, 1)

@@ -529,7 +529,10 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : 2;
         const int wide_cap = std::min(lin ? e->wide_lin_grid_blocks : e->grid_blocks, per_cu * e->prop.multiProcessorCount);
         const int wide_blocks = grid((count + 15) / 16, wide_cap);             // 4 tiles per wave
-        const int lin_blocks = grid((groups_needed + 3) / 4, e->lin_grid_blocks);
+        // two waves per SIMD already saturate the DP code (DESIGN 5.0 "Resident waves"): a launch that shares the machine
+        // takes two blocks per CU of the three that fit -- the next launch's blocks get in sooner, a third less workspace is live
+        const int lin_cap = (shared_machine && ln.stream == sl.stream) ? std::max(1, e->lin_grid_blocks * 2 / 3) : e->lin_grid_blocks;
+        const int lin_blocks = grid((groups_needed + 3) / 4, lin_cap);
         hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, ln.stream, kp,
                            e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws);
         HIP_TRY(hipGetLastError());

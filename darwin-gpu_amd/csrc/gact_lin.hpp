@@ -82,6 +82,13 @@ __device__ __forceinline__ uint32_t pk_max3f(uint32_t a, uint32_t b, uint32_t c)
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// (a & ~b) | c in one fast-class instruction (v_bitop3_b32, gfx950; truth table over a = 0xF0, b = 0xCC, c = 0xAA)
+__device__ __forceinline__ uint32_t andn_or(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xba" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t pk_ashr2(uint32_t a)
 {
     uint32_t r;
@@ -209,7 +216,8 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     constexpr int LAG = kGroup;
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
     const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), onev = vconst(kc.one),
-                   dtv = vconst(kc.next4 + kc.tag2);               // 4|g| + 2: H'' tagged 3 -> D'' tagged 1
+                   dtv = vconst(kc.next4 + kc.tag1),               // 4|g| + 1: G'' (tagged 2) -> D'' tagged 1
+                   c2v = vconst(kc.tag2), lut1v = vconst(0x01010101u);
     // zero level of the row a lane did "before step 1": region 1 is at row t - gl, region 2 at row t - gl - LAG
     uint32_t Z1 = pk2(lin_base(g) + gl * g), Z2 = pk2(lin_base(g) + (gl + LAG) * g);
     uint32_t G[CT];                         // H of the previous row (drifted)
@@ -243,21 +251,20 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         GACT_SB();
 #pragma unroll
         for (int c = 0; c < CT; c++) U[c] = (c == 0 ? Hdiag1 : c == C1 ? Hdiag2 : G[c - 1]) + P[c];   // align.cpp:134-144
-        if (tag2) {
-#pragma unroll
-            for (int c = C1; c < CT; c++) P[c] = G[c] - onev;                    // H_up tagged 2
-        }
+        // (pointer phase: region 2's G is kept tagged 2, so it IS H_up'' as it stands; the look-up words of that phase
+        //  carry a +1, so M'' = G_diag'' + 4 (sub - g) + 1 comes out tagged 3 with no instruction of its own)
+        (void)tag2;
         GACT_SB();
         if (GACT_LIN_MAX3) {
 #pragma unroll
             for (int c = 0; c < CT; c++)                                         // :145-147 and the insertion, :149-154
-                U[c] = pk_max3f(U[c], c < C1 ? Z1 : Zr2, (tag2 && c >= C1) ? P[c] : G[c]);
+                U[c] = pk_max3f(U[c], c < C1 ? Z1 : Zr2, G[c]);
         } else {
 #pragma unroll
             for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], c < C1 ? Z1 : Zr2);     // :145-147
             GACT_SB();
 #pragma unroll
-            for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], (tag2 && c >= C1) ? P[c] : G[c]);    // the insertion, :149-154
+            for (int c = 0; c < CT; c++) U[c] = pk_max(U[c], G[c]);              // the insertion, :149-154
         }
         GACT_SB();
     };
@@ -288,14 +295,16 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     };
 
-    // ---- pointer phase: region 2 on tagged scores; G = 4H + 3 there
+    // ---- pointer phase: region 2 on tagged scores; G = 4H + 2 there: H_up'' without an instruction, the diagonal gets
+    //      its tag 3 from the look-up word (+1), the left neighbour its tag 1 from the gap subtraction (4|g| + 1), and
+    //      "low bits := 2" is one fast-class v_bitop3_b32
     uint32_t Z24 = 0;
     auto step_tagged = [&](const int t) {
         const uint32_t w1 = ref16[t + 1], w2 = ref16[t + 1 - LAG];
         Z1 += gv; Z24 += g4v;
         const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
-        // lane 15's region-1 column enters region 2 scaled and tagged 3
-        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4v(H1, c3v)));
+        // lane 15's region-1 column enters region 2 scaled and tagged 2
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4v(H1, c2v)));
         uint32_t U[CT];
         upper_all(U, true, Z24);
         Hdiag1 = Hl1; Hdiag2 = Hl2;
@@ -305,30 +314,30 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         for (int c = 0; c < C2; c++) {
             const bool both = c < C1;
             uint32_t Da = 0;
-            const uint32_t Db = Hb - dtv;                                        // H'' tagged 3 -> D'' tagged 1
+            const uint32_t Db = Hb - dtv;                                        // G'' tagged 2 -> D'' tagged 1
             if (both) Da = Ha - gv;
             GACT_SB();
             const uint32_t Hp = pk_max(U[C1 + c], Db);                           // the low bits: the op (:162-164)
             if (both) { G[c] = pk_max(U[c], Da); Ha = G[c]; }
             if (c > 0) acc[c - 1] = pk_shl_add4(acc[c - 1], tprev);
             GACT_SB();
-            G[C1 + c] = Hp | c3v;
+            G[C1 + c] = andn_or(Hp, c3v, c2v);                                   // low bits := 2
             tprev = Hp & c3v;
             GACT_SB();
             Hb = G[C1 + c];
         }
         acc[C2 - 1] = pk_shl_add4(acc[C2 - 1], tprev);
         H1 = Ha; H2 = Hb;
-        rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8);
+        rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu) + lut1v; rb2b = lut4(w2 >> 8) + lut1v;
     };
 #undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
-        for (int c = C1; c < CT; c++) G[c] = pk_mad4v(G[c], c3v);
-        H2 = pk_mad4v(H2, c3v);
-        Hdiag2 = pk_mad4v(Hdiag2, c3v);
-        Z24 = pk_mad4v(Z2, c3v);
-        rb2 = rb2 << 2; rb2b = rb2b << 2;               // the row already fetched: bonus times four
+        for (int c = C1; c < CT; c++) G[c] = pk_mad4v(G[c], c2v);
+        H2 = pk_mad4v(H2, c2v);
+        Hdiag2 = pk_mad4v(Hdiag2, c2v);
+        Z24 = pk_mad4v(Z2, c3v);                        // the zero level stays tagged 3 (H == 0 reads as MATCH, see 3.)
+        rb2 = (rb2 << 2) + lut1v; rb2b = (rb2b << 2) + lut1v;      // the row already fetched: bonus times four, + 1
     };
 
     int t = 1;
@@ -391,7 +400,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) { atomicAdd(&g_flush_clocks[0], fl_clk); atomicAdd(&g_flush_clocks[1], fl_n); atomicAdd(&g_flush_clocks[2], fl_st); }
 #endif
     // H of the last column at the row of the last step, drift taken off
-    return tagged ? pk_ashr2(pk_sub(H2, Z24)) : pk_sub(H2, Z2);
+    return tagged ? pk_ashr2(pk_sub(H2 | kc.c3, Z24)) : pk_sub(H2, Z2);
 }
 
 // ---------------------------------------------------------------------------

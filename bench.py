@@ -77,13 +77,14 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
 # wave64 VALU instruction; the kernels work on int16 pairs, two cells per slot.  Per cell PAIR the recurrence of
 # align.cpp:134-160 needs, in the cheapest formulation known for the scoring in use,
 #   affine gaps (any scoring):          11 ops for the scores, 11 more where traceback pointers are made
-#   linear gaps (open == extend == mismatch, the reference's params.cfg): 5 and 4 more (gact_lin.hpp: H alone,
-#                                                 two of its three maxima in one v_pk_maximum3_f16, op-only pointers)
+#   linear gaps (open == extend == mismatch, the reference's params.cfg): 5 and 3 more (gact_lin.hpp: H alone,
+#                                                 two of its three maxima in one v_pk_maximum3_f16, op-only pointers,
+#                                                 the H_up tag for free since round 3's v_bitop3_b32 form)
 # and pointers are needed only inside the window a non-first tile's traceback can reach: early x early of
 # tile x tile cells (align.cpp:205), 0.39 at the reference's 320 / 120.  Nothing else is counted: no wavefront
 # skew, no loads, no traceback walk, no chain bookkeeping -- those are what `frac` is there to expose.
 def floor_slots_per_cell(linear, tile, early):
-    score, pointer = (5, 4) if linear else (11, 11)
+    score, pointer = (5, 3) if linear else (11, 11)
     window = (min(early, tile) / tile) ** 2
     return (score + pointer * window) / 2.0, {"score_ops_per_cell_pair": score, "pointer_ops_per_cell_pair": pointer,
                                               "pointer_window_fraction": round(window, 4)}
@@ -333,7 +334,7 @@ def main():
             # achieved = algorithmic lane-op slots (model below) x cells of the main launch / its HIP-event time;
             # peak = the SIMDs' issue rate; frac <= 1 by construction = (floor / executed slots per cell) x utilisation.
             # The floor is the cheapest formulation KNOWN for the scoring in use and has moved between rounds
-            # (4.87 -> 3.78 -> 3.28 slots per cell): compare rounds on valu_issue_utilisation, executed_slots_per_cell
+            # (4.87 -> 3.78 -> 3.28 -> 3.09 slots per cell): compare rounds on valu_issue_utilisation, executed_slots_per_cell
             # and survey_24op_int32, not on frac.
             "bound": "valu",
             "valu_issue_utilisation": executed["valu_issue_utilisation"] if executed else None,

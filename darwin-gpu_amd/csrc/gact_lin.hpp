@@ -426,7 +426,8 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
     const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), onev = vconst(kc.one),
-                   dtv = vconst(kc.next4 + kc.tag2);
+                   dtv = vconst(kc.next4 + kc.tag1),       // 4|g| + 1: G'' (tagged 2) -> D'' tagged 1
+                   c2v = vconst(kc.tag2), lut1v = vconst(0x01010101u);
     uint32_t Z = pk2(lin_base(g) + gl * g);      // zero level of the row this lane did "before step 1"
     uint32_t G[C];                               // H of the previous row (see dp_pass_lin_split)
     uint32_t acc[2 * NW];
@@ -468,20 +469,17 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         GACT_SB();
 #pragma unroll
         for (int c = 0; c < C; c++) U[c] = (c == 0 ? Hdiag : G[c - 1]) + P[c];                 // align.cpp:134-144
-        if (tag2) {
-#pragma unroll
-            for (int c = 0; c < C; c++) P[c] = G[c] - onev;                                    // H_up tagged 2
-        }
+        (void)tag2;                              // (pointer phase: G is kept tagged 2 = H_up'' as it stands, see dp_pass_lin_split)
         GACT_SB();
         if (GACT_LIN_MAX3) {
 #pragma unroll
-            for (int c = 0; c < C; c++) U[c] = pk_max3f(U[c], Zr, tag2 ? P[c] : G[c]);         // :145-147 and the insertion, :149-154
+            for (int c = 0; c < C; c++) U[c] = pk_max3f(U[c], Zr, G[c]);                       // :145-147 and the insertion, :149-154
         } else {
 #pragma unroll
             for (int c = 0; c < C; c++) U[c] = pk_max(U[c], Zr);                               // :145-147
             GACT_SB();
 #pragma unroll
-            for (int c = 0; c < C; c++) U[c] = pk_max(U[c], tag2 ? P[c] : G[c]);               // the insertion, :149-154
+            for (int c = 0; c < C; c++) U[c] = pk_max(U[c], G[c]);                             // the insertion, :149-154
         }
         GACT_SB();
     };
@@ -512,22 +510,22 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
             const uint32_t kb = row0 < (uint32_t)rows[1] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
             key_c = pk_sub(ka | (kb << 16), Z8);
         }
-        const uint32_t Hl0 = shr1(G_last, Z4);
+        const uint32_t Hl0 = shr1(G_last, Z4 - onev);       // j = 0 border: the zero level, tagged 2 like every G''
         uint32_t U[C];
         upper_all(U, true, Z4);
         Hdiag = Hl0;
         uint32_t Hl = Hl0, tprev = 0;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            const uint32_t Db = Hl - dtv;                                                       // H'' tagged 3 -> D'' tagged 1
+            const uint32_t Db = Hl - dtv;                                                       // G'' tagged 2 -> D'' tagged 1
             GACT_SB();
             const uint32_t Hp = pk_max(U[c], Db);                                               // the low bits: the op (:162-164)
             if (c > 0) {
                 acc[c - 1] = pk_shl_add4(acc[c - 1], tprev);
-                if (AMAX) bk[c - 1] = pk_max(bk[c - 1], pk_mad_vvv(G[c - 1], kc.tag2, key_c)); // 2 G'' + (step & 7) - 2 Z''
+                if (AMAX) bk[c - 1] = pk_max(bk[c - 1], pk_mad_vvv(G[c - 1], kc.tag2, key_c)); // 2 G'' + (step & 7) - Z8
             }
             GACT_SB();
-            G[c] = Hp | c3v;
+            G[c] = andn_or(Hp, c3v, c2v);                                                       // low bits := 2
             tprev = Hp & c3v;
             GACT_SB();
             Hl = G[c];
@@ -535,17 +533,17 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
         acc[C - 1] = pk_shl_add4(acc[C - 1], tprev);
         if (AMAX) bk[C - 1] = pk_max(bk[C - 1], pk_mad_vvv(G[C - 1], kc.tag2, key_c));
         G_last = Hl;
-        lutA = lut4(w_next & 0xffu); lutB = lut4(w_next >> 8);
+        lutA = lut4(w_next & 0xffu) + lut1v; lutB = lut4(w_next >> 8) + lut1v;
     };
 #undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
-        for (int c = 0; c < C; c++) G[c] = pk_mad4v(G[c], c3v);
-        G_last = pk_mad4v(G_last, c3v);
-        Hdiag = pk_mad4v(Hdiag, c3v);
-        Z4 = pk_mad4v(Z, c3v);
-        Z8 = Z4 + Z4;
-        lutA <<= 2; lutB <<= 2;
+        for (int c = 0; c < C; c++) G[c] = pk_mad4v(G[c], c2v);
+        G_last = pk_mad4v(G_last, c2v);
+        Hdiag = pk_mad4v(Hdiag, c2v);
+        Z4 = pk_mad4v(Z, c3v);                          // the zero level itself stays tagged 3
+        Z8 = Z4 + Z4 - c2v;                             // 8 Z + 4 = twice a zero-score G'': the keys are 8 (H - Z) + (step & 7)
+        lutA = (lutA << 2) + lut1v; lutB = (lutB << 2) + lut1v;
     };
 
     // fold the block keys of stored steps kblk..kblk+7 into lane_best (as dp_pass_p16)
@@ -620,7 +618,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 #pragma unroll
     for (int c = 1; c < C; c++) { ga = (c == cqA) ? G[c] : ga; gb = (c == cqB) ? G[c] : gb; }
     const uint32_t pick = __builtin_amdgcn_perm(gb, ga, 0x07060100u);           // {tile B's half of gb, tile A's half of ga}
-    return tagged ? pk_ashr2(pk_sub(pick, Z4)) : pk_sub(pick, Z);
+    return tagged ? pk_ashr2(pk_sub(pick | kc.c3, Z4)) : pk_sub(pick, Z);
 }
 
 // The wide main launch of linear scorings: UniformLayout<10, 32>'s column map, the pass above, FMT 3 words

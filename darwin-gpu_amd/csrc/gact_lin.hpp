@@ -21,6 +21,8 @@
 //    came from -- M 3, H_up 2, H_left 1: the numbering of align.h:23, and the tie order of align.cpp:162-164 is the
 //    order of the tags:
 //      H'' = max(M'' | 3, Z'', H''_up - 1, H''_left - (4|g| + 2)),     op = H'' & 3,     stored: G = H'' | 3
+//    (as of round 3 the stored form is G = (H'' & ~3) | 2 -- it is H''_up - 1 as it stands -- with the diagonal's tag
+//    coming from a +1 in the look-up word and the left neighbour's from 4|g| + 1: see dp_pass_lin_split)
 //    -- 10 instructions per pair with the two that shift the op into its column's half-word.  No open / extend flags
 //    are made: the walker does not need them (walk_chain_lin, gact_chain.hpp: with these scorings the next state of
 //    the traceback is the op of the cell it enters).  H == 0 shows as op 3 like MATCH (M'' is clamped to the zero

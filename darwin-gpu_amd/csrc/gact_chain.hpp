@@ -28,6 +28,7 @@ struct ChainState {
     int open_flag;                // right phase: the reference's `open`
     int n_tiles;
     int comp;                     // candidate aligns against the reverse-complemented query set
+    int full;                     // linear-gap passes: the next tile stores its whole pointer window (its banded run gave up)
     int64_t cells;
 };
 
@@ -57,7 +58,7 @@ __device__ __forceinline__ void chain_begin(ChainState &s, int cand, const gact_
     s.i = 0; s.j = 0; s.first_tile = 1; s.first_tile_score = 0;
     s.phase = 0; s.brk = 0;
     s.score = 0; s.pend_gap = 0; s.have_left = 0; s.left_first_gap = 0; s.open_flag = 1;
-    s.n_tiles = 0; s.cells = 0;
+    s.n_tiles = 0; s.cells = 0; s.full = 0;
 }
 
 __device__ __forceinline__ void chain_write_record(const ChainState &s, int same_file, gact_overlap *out)
@@ -186,7 +187,7 @@ template <int CW, int QN, int ROW>
 __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                                int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                                const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
-                                               int &nst, int v0, const uint32_t *ws_all)
+                                               int &nst, int v0, const uint32_t *ws_all, const int band_lim, bool &redo)
 {
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     constexpr uint32_t kM = 3u, kI = 2u, kD = 1u;               // align.h:23 numbering, as the pass tags them
@@ -249,13 +250,19 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
         const int c = p + __mul24(l, -CW);
         const int k = imax(kA + l + nis, 0);
-        if ((it & 7) == 7) refill(l, c, k);
+        if ((it & 7) == 7) {
+            refill(l, c, k);
+            // banded stores (gact_lin.hpp LinBand): words are there for |di - dj| <= band.  The next eight moves change
+            // di - dj by eight at most: further out than band - 8 here, the walk gives up and its tile is run again with
+            // every block stored (band_lim = band - 8; negative: the tile stored everything)
+            redo = redo | ((band_lim >= 0) & ((unsigned)(nis - njs + band_lim) > (unsigned)(2 * band_lim)));
+        }
         // the op and the bases of the cell just entered: three LDS reads in flight together.  The op is the next
         // state whatever the move was (see above); ZERO is only asked for after a diagonal move (align.cpp:211-212
         // against :219, :225); the step limit and the borders: align.cpp:205, :101-107
         cur = fetch(l, c, k);
         rbase = ra[nis * rstride]; qbase = qa[njs];
-        go = !((diag && v == 0) || nis <= nlim_i || njs <= nlim_j);
+        go = !((diag && v == 0) || nis <= nlim_i || njs <= nlim_j || redo);
     }
 #ifdef GACT_STAMPS_REFILL
     if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_refill_clocks, rf_clk);
@@ -293,6 +300,7 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
 // what a walk is made of now (the words of a 200 x 200 window are 14 KB per tile, 43 MB per XCD in flight: they come
 // back from beyond the L2, ~3,500 clocks each time), and every team of the wave takes its refill at the same trip.
 constexpr int kLaTeam = 8;
+constexpr int kLaBandMargin = 12, kWalkBandMargin = 8;      // how far inside the stored band a walk must be when it refills (team / one lane)
 #ifndef GACT_WALK_SYNC_REFILL
 #define GACT_WALK_SYNC_REFILL 1
 #endif
@@ -311,7 +319,8 @@ template <int CW, int QN, int ROW, int SPAN>
 __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const bool active, int R, int Q, int l0, int c0, int k0,
                                                     int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                                     const KParams &kp, ScoreWalk &wk, int &ref_steps, int &query_steps,
-                                                    int &nst, int v0, const uint32_t *ws, const uint32_t *ws_all)
+                                                    int &nst, int v0, const uint32_t *ws, const uint32_t *ws_all,
+                                                    const int band_lim, bool &redo)
 {
     using RG = LaRegion<CW, QN, SPAN>;
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
@@ -430,6 +439,9 @@ __device__ __forceinline__ void walk_chain_lin_team(uint32_t *scratch, const boo
 #ifdef GACT_STAMPS_REFILL
             const unsigned long long rf_t0 = __builtin_amdgcn_s_memtime();
 #endif
+            // banded stores (see walk_chain_lin): between two re-anchorings the head moves RG::kRefill + 1 rows or columns
+            // at most, so di - dj changes by no more than that (band_lim = band - kLaBandMargin)
+            if ((band_lim >= 0) & ((unsigned)(nis - njs + band_lim) > (unsigned)(2 * band_lim))) { redo = true; go = false; }
             refill(lh, imax(kA + lh + nis, 0));
 #ifdef GACT_STAMPS_REFILL
             rf_clk += __builtin_amdgcn_s_memtime() - rf_t0;
@@ -489,11 +501,14 @@ template <int CW, int FMT, int QN = CW / 4, int ROW = kGroup>
 __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                            int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
                                            int phase, const KParams &kp, ScoreWalk &wk, int &ref_steps,
-                                           int &query_steps, int &nst, int v0 = 0, const uint32_t *ws_all = nullptr)
+                                           int &query_steps, int &nst, int v0 = 0, const uint32_t *ws_all = nullptr,
+                                           const int band_lim = -1, bool *redo = nullptr)
 {
     if constexpr (FMT == 3) {
+        bool rd = false;
         walk_chain_lin<CW, QN, ROW>(ws, scratch, R, Q, l0, c0, k0, early, rrow, rstride, qrow, kp, wk, ref_steps,
-                                      query_steps, nst, v0, ws_all);
+                                      query_steps, nst, v0, ws_all, band_lim, rd);
+        if (redo) *redo = rd;
         return;
     }
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
@@ -630,6 +645,7 @@ struct ChainQueues {
     // routing by read content (align.cpp:134 compares raw bytes: N == N, case matters): route_kernel (gact_kernels.hpp)
     // sorts the candidates of a run into those whose two reads are plain A/C/G/T and the rest; a seed launch then takes
     // one of the two lists
+    int *band_redos;             // tiles run a second time because their walk left the stored band (gact_lin.hpp LinBand)
     const int *list_count;       // null: the seed launch takes the candidates [first, first + n) themselves
     const int *list;             // candidate indices
 };

@@ -51,6 +51,8 @@ struct KParams {
     int32_t ws_words;         // workspace dwords per group
     int32_t prio_bases[2];    // main launch: chains with more bases left than this run their DP at priority 1 / 2;
                               // {0, 0}: rank against the longest chain running right now instead (longest_running)
+    int32_t band;             // linear-gap main launch: pointer words are stored within `band` columns of the diagonal through
+                              // a tile's (R, Q) only (gact_lin.hpp LinBand); 0: the whole window
 };
 
 template <int C> struct Geometry {

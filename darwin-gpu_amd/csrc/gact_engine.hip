@@ -325,7 +325,8 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
     return 0;
 }
 
-// d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [4] / [5] candidates routed to the 2-bit / the raw-byte launches, [8..8+kBuckets) bucket_count,
+// d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [4] / [5] candidates routed to the 2-bit / the raw-byte launches,
+// [6] tiles run twice because their walk left the stored band (gact_lin.hpp LinBand), [8..8+kBuckets) bucket_count,
 // [8+kBuckets..8+2*kBuckets) bucket_pop
 constexpr int kCounterInts = 8 + 2 * gact::kBuckets + gact::kEpochs;
 
@@ -354,6 +355,7 @@ gact::ChainQueues queues(const Lane &ln, Slot &sl)
     q.live_stride = (int)(ln.live_cap / gact::kBuckets);
     q.states = sl.chain_states.p;
     q.longest_now = ln.d_counter + 8 + 2 * gact::kBuckets;
+    q.band_redos = ln.d_counter + 6;
     q.list_count = nullptr;
     q.list = nullptr;
     return q;
@@ -711,6 +713,9 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     if (p->device_id < 0 || p->device_id >= ndev)
         return fail(GACT_HIP_EINVAL, "device_id %d not in [0,%d)", p->device_id, ndev);
 
+#ifdef GACT_EXPERIMENTS
+    fprintf(stderr, "[gact_hip] built with -DGACT_EXPERIMENTS: timing experiments may be compiled in, results are NOT to be trusted\n");
+#endif
     gact_hip_engine *e = new gact_hip_engine();
     e->params = *p;
     int rc = set_device(e);
@@ -747,6 +752,22 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
     if (const char *v = getenv("GACT_HIP_WIDE_BLOCKS_PER_CU")) e->wide_blocks_per_cu = atoi(v);
     e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;
+    // pointer words of the linear-gap main launch are stored within `band` columns of the diagonal through a tile's (R, Q);
+    // a walk that comes within a refill of its edge has its tile run again with the whole window (exact either way).
+    // GACT_HIP_BAND=<n>: another width (tests: a narrow one exercises the second runs); 0: the whole window, as before round 4
+    e->kp.band = gact::kLinBandDefault;
+    if (const char *v = getenv("GACT_HIP_BAND")) {
+        const int b = atoi(v);
+        e->kp.band = b <= 0 ? 0 : std::max(b, gact::kLinBandMin);
+    }
+    if (e->kp.band >= e->kp.early) e->kp.band = 0;             // (as wide as the window: nothing to leave out)
+    // lanes store in aligned groups of 1, 4 or 8 (64 / 128 bytes of a workspace row): bits 16.. of kp.band
+    {
+        int q = gact::kLinBandQuantum;
+        if (const char *v = getenv("GACT_HIP_BAND_QUANTUM")) q = atoi(v);
+        q = q >= 8 ? 8 : q >= 4 ? 4 : q >= 2 ? 2 : 1;
+        if (e->kp.band) e->kp.band |= q << 16;
+    }
     static_assert(gact::GeometrySplit<7, 13>::kWsWords <= gact::Geometry<20>::kWsWords, "workspace too small");
     e->kc.match = gact::pk2(p->match); e->kc.nd = gact::pk2(p->mismatch - p->match);
     e->kc.open = gact::pk2(p->gap_open); e->kc.ext = gact::pk2(p->gap_extend);
@@ -1197,6 +1218,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
         st->handed_off = 0;
         for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b];
         memcpy(&st->seed_cells, &c[2], sizeof(int64_t));
+        st->band_redos = c[6];
         if (sl.side_used) {                 // launches beside: their share of both figures
             HIP_TRY(hipMemcpy(c, sl.side_counter, sizeof c, hipMemcpyDeviceToHost));
             for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b];

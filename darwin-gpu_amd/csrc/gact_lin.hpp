@@ -105,19 +105,12 @@ template <int CW> struct LinWords {
     static constexpr int kWords = (CW + 1) / 2;          // dwords per lane, tile and flush
     static constexpr int kUint4 = (kWords + 3) / 4;
 };
-#ifdef GACT_STAMPS_FLUSH
-__device__ unsigned long long g_flush_clocks[3];     // diagnostic: shader clocks inside the split pass's flushes, their number, clocks of the stores alone
-#define g_flush_mid fl_mid_
-#endif
-// acc[c]: the codes of column c, tile A in the low half-word, tile B in the high one
+// acc[c]: the codes of column c, tile A in the low half-word, tile B in the high one.  storeA / storeB: does this lane
+// write its words of tile A / tile B for this flush block (LinBand below: the block meets the band a walk can reach, or
+// the tile stores everything)
 template <int NW, int LANES, class Fix>
-__device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *qA, uint4 *qB, Fix fix, const bool store = true,
-                                          unsigned long long *mid = nullptr)
+__device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *qA, uint4 *qB, Fix fix, const bool storeA, const bool storeB)
 {
-#ifdef GACT_STAMPS_FLUSH
-    unsigned long long fl_mid_ = 0;
-    struct MidOut { unsigned long long *dst, &v; __device__ ~MidOut() { if (dst) *dst = v; } } mid_out_{mid, fl_mid_};
-#endif
     constexpr int QD = (NW + 3) / 4;
     uint32_t wa[QD * 4], wb[QD * 4];
 #pragma unroll
@@ -125,82 +118,37 @@ __device__ __forceinline__ void lin_flush(const uint32_t (&acc)[2 * NW], uint4 *
         wa[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x05040100u)) : 0u;
         wb[n] = n < NW ? fix(__builtin_amdgcn_perm(acc[n < NW ? 2 * n + 1 : 0], acc[n < NW ? 2 * n : 0], 0x07060302u)) : 0u;
     }
-    if (!store) return;          // a lane whose columns no walk can reach (uniform layout, non-first tiles)
-#if GACT_EXP_SPLIT_FLUSH
-    // timing experiment (wrong results): `mid` misused as a selector -- (void *)1: tile A's words only, (void *)2: tile B's
-    if (mid == (unsigned long long *)1 || mid == (unsigned long long *)2) {
-        const bool a_only = mid == (unsigned long long *)1;
-        uint32_t x = 0;
+    if (storeA) {
 #pragma unroll
-        for (int n = 0; n < QD * 4; n++) x ^= a_only ? wb[n] : wa[n];
-        asm volatile("" :: "v"(x));
-#pragma unroll
-        for (int q = 0; q < QD; q++) {
-            if (a_only) qA[q * kWsRow] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
-            else qB[q * kWsRow] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
-        }
-        return;
+        for (int q = 0; q < QD; q++) qA[q * kWsRow] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
     }
-#endif
-#ifdef GACT_STAMPS_FLUSH
-    {
-        uint32_t x = 0;
+    if (storeB) {
 #pragma unroll
-        for (int n = 0; n < QD * 4; n++) x ^= wa[n] ^ wb[n];
-        asm volatile("" :: "v"(x));                       // the re-paired words exist before the clock is read
-        g_flush_mid = __builtin_amdgcn_s_memtime();
+        for (int q = 0; q < QD; q++) qB[q * kWsRow] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
     }
-#endif
-#if GACT_EXP_STORE_CONST
-    // timing experiment (wrong results): the same stores, but of registers nobody writes again -- are the stores dear
-    // because the step that follows overwrites their data registers while they are still pending?
-    {
-        uint32_t x = 0;
-#pragma unroll
-        for (int n = 0; n < QD * 4; n++) x ^= wa[n] ^ wb[n];
-        asm volatile("" :: "v"(x));
-        const uint32_t k0 = (uint32_t)(uintptr_t)qA, k1 = (uint32_t)(uintptr_t)qB;
-#pragma unroll
-        for (int q = 0; q < QD; q++) {
-            qA[q * kWsRow] = make_uint4(k0, k1, k0, k1);
-            qB[q * kWsRow] = make_uint4(k1, k0, k1, k0);
-        }
-    }
-#elif GACT_PTR_BUFFER_STORE
-    // the same four stores as buffer_store_dwordx4 through a raw buffer descriptor over the wave's workspace
-    // (GACT_PTR_BUFFER_STORE == 2, timing experiment: a descriptor of zero records -- the range check drops the stores)
-    {
-        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-        const uint64_t base = (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)qA) |
-                              ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)qA >> 32)) << 32);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, GACT_PTR_BUFFER_STORE == 2 ? 0 : 0x7fffff00, 0x00020000);
-        const int oa = (int)((uintptr_t)qA - base), ob = (int)((uintptr_t)qB - base);
-#pragma unroll
-        for (int q = 0; q < QD; q++) {
-            const u32x4_t da = {wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]};
-            const u32x4_t db = {wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]};
-            __builtin_amdgcn_raw_buffer_store_b128(da, rs, oa + q * kWsRow * 16, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(db, rs, ob + q * kWsRow * 16, 0, 0);
-        }
-    }
-#elif GACT_EXP_STORE_ONE == 1
-    // timing experiment (wrong results): ONE of the stores of a flush
-    {
-        uint32_t x = 0;
-#pragma unroll
-        for (int n = 4; n < QD * 4; n++) x ^= wa[n];
-#pragma unroll
-        for (int n = 0; n < QD * 4; n++) x ^= wb[n];
-        asm volatile("" :: "v"(x));
-        qA[0] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
-    }
-#else
-#pragma unroll
-    for (int q = 0; q < QD; q++) {
-        qA[q * kWsRow] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
-        qB[q * kWsRow] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
-    }
-#endif
+}
+
+// 6. Banded pointer stores (round 4).  A non-first tile's traceback starts at (R, Q) and moves up and to the left
+//    (align.cpp:205-229); with di = R - i and dj = Q - j every move changes di - dj by at most one, and at the error rates
+//    this aligner is made for the path stays within a few tens of columns of the diagonal di == dj for all of its <= 2 x early
+//    steps.  The pass therefore stores, per lane, only the flush blocks that hold a cell with |di - dj| <= band -- about a
+//    third of the window's 14 KB per tile -- and the walker checks at every region refill that it is still at least a
+//    refill's worth of steps inside the band (walk_chain_lin, gact_chain.hpp).  A walk that is not gives up; its tile is run
+//    again with every block stored (ChainState::full), the one case in some hundreds: exact by construction, whatever the
+//    reads look like.  Every tile of a wave ends on the wave's last step (kEndAligned), so a cell's step is
+//    T_end - di - (lanes between its lane and the lane of column Q): lane by lane a range of steps, [lo, hi].
+constexpr int kLinBandDefault = 48, kLinBandMin = 24, kLinBandQuantum = 1;
+struct LinBand {
+    int lo[2], hi[2];          // steps whose cells of this lane lie inside the band, tile A / tile B (lo > hi: none)
+    bool full[2];              // the tile stores every block of the window
+    __device__ __forceinline__ bool store(int h, int first, int last) const { return full[h] | ((last >= lo[h]) & (first <= hi[h])); }
+};
+// lane's columns are dj_min .. dj_max away from column Q (dj_max < 0: pads right of the tile), `behind` lanes before Q's
+__device__ __forceinline__ void lin_band_range(LinBand &b, int h, int T_end, int behind, int dj_min, int dj_max, int band, bool full)
+{
+    b.full[h] = full | (band <= 0);
+    b.lo[h] = T_end - behind - dj_max - band;
+    b.hi[h] = dj_max < 0 ? -0x40000000 : T_end - behind - imax(dj_min, 0) + band;
 }
 
 // ---------------------------------------------------------------------------
@@ -211,7 +159,8 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
                                                       const uint16_t *__restrict__ ref16,
                                                       const uint32_t (&qb)[C1 + C2],
                                                       const int T_end, const int tB,
-                                                      uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB)
+                                                      uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
+                                                      const int band, const bool fullA, const bool fullB)
 {
     constexpr int CT = C1 + C2;
     constexpr int NW = LinWords<C2>::kWords, QD = LinWords<C2>::kUint4;
@@ -348,59 +297,38 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     if (tagged) enter_tagged();
     uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
     uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
-    // (GACT_EXP_NO_STORE, timing experiment: the words are made but not stored -- a condition the compiler cannot see through)
-    const bool exp_store = !GACT_EXP_NO_STORE || kc.one == 0x7ffe7ffeu;
-    auto flush = [&](auto fix) { lin_flush<NW, kGroup>(acc, qA, qB, fix, exp_store); };
+    // region 2 is right-aligned: lane gl's columns are 13 (15 - gl) .. 13 (15 - gl) + 12 away from column Q in EVERY tile
+    // (quantum: lanes store in aligned groups of 1, 4 or 8 -- whole 64- or 128-byte pieces of a workspace row -- so that the
+    //  walker's loads never meet a partly written cache line; both ends of a lane's range grow with the lane)
+    LinBand bd;
+    {
+        const int q1 = (band >> 16) - 1, b = band & 0xffff;
+        const int u_lo = kGroup - 1 - (gl & ~q1), u_hi = kGroup - 1 - (gl | q1);
+        LinBand lo_, hi_;
+        lin_band_range(lo_, 0, T_end, u_lo, C2 * u_lo, C2 * u_lo + C2 - 1, b, fullA);
+        lin_band_range(hi_, 0, T_end, u_hi, C2 * u_hi, C2 * u_hi + C2 - 1, b, fullA);
+        bd.lo[0] = bd.lo[1] = lo_.lo[0]; bd.hi[0] = bd.hi[1] = hi_.hi[0];
+        bd.full[0] = fullA | (b <= 0); bd.full[1] = fullB | (b <= 0);
+    }
+#if GACT_EXP_NO_STORE
+    if (kc.one != 0x7ffe7ffeu) { bd.full[0] = bd.full[1] = false; bd.lo[0] = bd.lo[1] = 1; bd.hi[0] = bd.hi[1] = 0; }   // (timing experiment: no stores)
+#endif
     // whole blocks of eight steps, each followed by its flush (an `if ((k & 7) == 7)` inside one loop is
     // if-converted by the compiler: the re-pairing v_perm of the flush would then run at every step)
     int k = 0;
-#ifdef GACT_STAMPS_FLUSH
-    unsigned long long fl_clk = 0, fl_n = 0, fl_st = 0;
-#endif
     while (t + 7 <= T_end) {
-#if GACT_EXP_SPLIT_FLUSH
-        // timing experiment (wrong results): two flush events of half the bytes per eight steps
-        for (int s8 = 0; s8 < 4; s8++, t++) step_tagged(t);
-        lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, exp_store, (unsigned long long *)2);
-        for (int s8 = 0; s8 < 4; s8++, t++) step_tagged(t);
-        lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, exp_store, (unsigned long long *)1);
-        k += 8;
-        qA += QD * kWsRow;
-        qB += QD * kWsRow;
-        continue;
-#elif GACT_EXP_FLUSH16
-        // timing experiment (wrong results): every other flush left out -- half the events, half the bytes
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
-        if (k & 8) { flush([](uint32_t w) { return w; }); }
+        lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, bd.store(0, t - 8, t - 1), bd.store(1, t - 8, t - 1));
         qA += QD * kWsRow;
         qB += QD * kWsRow;
-        continue;
-#endif
-        for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
-        k += 8;
-#ifdef GACT_STAMPS_FLUSH
-        { const unsigned long long f0 = __builtin_amdgcn_s_memtime();
-          unsigned long long fm = 0;
-          lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, exp_store, &fm);
-          const unsigned long long f1 = __builtin_amdgcn_s_memtime();
-          fl_clk += f1 - f0; fl_n++; if (fm) fl_st += f1 - fm; }
-#else
-        flush([](uint32_t w) { return w; });
-#endif
-#if !GACT_EXP_STORE_HOME
-        qA += QD * kWsRow;
-        qB += QD * kWsRow;
-#endif
     }
     for (; t <= T_end; t++, k++) step_tagged(t);
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
-        flush([sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); });
+        lin_flush<NW, kGroup>(acc, qA, qB, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); },
+                              bd.store(0, t - (k & 7), t - 1), bd.store(1, t - (k & 7), t - 1));
     }
-#ifdef GACT_STAMPS_FLUSH
-    if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) { atomicAdd(&g_flush_clocks[0], fl_clk); atomicAdd(&g_flush_clocks[1], fl_n); atomicAdd(&g_flush_clocks[2], fl_st); }
-#endif
     // H of the last column at the row of the last step, drift taken off
     return tagged ? pk_ashr2(pk_sub(H2 | kc.c3, Z24)) : pk_sub(H2, Z2);
 }
@@ -420,11 +348,29 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
                                                 const int T_end, const int tB,
                                                 uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
                                                 const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb,
-                                                const int col_from)
+                                                const int col_from, const int band, const int QA, const int QB,
+                                                const bool fullA, const bool fullB)
 {
     constexpr int NW = LinWords<C>::kWords, QD = LinWords<C>::kUint4;
     // col_from: first column (1-based) a walk can reach in either tile: lanes left of it keep their words
     const bool store = (AMAX || gl * C + C >= col_from) && (!GACT_EXP_NO_STORE || kc.one == 0x7ffe7ffeu);
+    // band (non-first tiles, see LinBand): the lane's columns gl C + 1 .. gl C + C are Q - gl C - C .. Q - gl C - 1 away from
+    // column Q, whose lane is (Q - 1) / C
+    LinBand bd;
+    {
+        const int q1 = AMAX ? 0 : (band >> 16) - 1, b = AMAX ? 0 : band & 0xffff;     // (quantum: see dp_pass_lin_split)
+        const int g_lo = gl & ~q1, g_hi = gl | q1;
+        LinBand lo_, hi_;
+        lin_band_range(lo_, 0, T_end, (imax(QA, 1) - 1) / C - g_lo, QA - g_lo * C - C, QA - g_lo * C - 1, b, fullA);
+        lin_band_range(lo_, 1, T_end, (imax(QB, 1) - 1) / C - g_lo, QB - g_lo * C - C, QB - g_lo * C - 1, b, fullB);
+        lin_band_range(hi_, 0, T_end, (imax(QA, 1) - 1) / C - g_hi, QA - g_hi * C - C, QA - g_hi * C - 1, b, fullA);
+        lin_band_range(hi_, 1, T_end, (imax(QB, 1) - 1) / C - g_hi, QB - g_hi * C - C, QB - g_hi * C - 1, b, fullB);
+        bd = lo_;
+        // (the quantum's highest lane may lie right of the tile -- dj_max < 0, nothing of its own to store: its hi is then the
+        //  last step)
+        bd.hi[0] = hi_.hi[0] < 0 ? (lo_.hi[0] < 0 ? lo_.hi[0] : T_end) : hi_.hi[0];
+        bd.hi[1] = hi_.hi[1] < 0 ? (lo_.hi[1] < 0 ? lo_.hi[1] : T_end) : hi_.hi[1];
+    }
     static_assert(!AMAX || LANES == kGroup, "first tiles run on the 16-lane layout");
     const int g = (int)(int16_t)(kc.ext & 0xffffu);
     const uint32_t gv = vconst(kc.next), g4v = vconst(kc.next4), c3v = vconst(kc.c3), onev = vconst(kc.one),
@@ -580,7 +526,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     while (t + 7 <= T_end) {                     // whole blocks of eight steps + flush (see dp_pass_lin_split)
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
-        lin_flush<NW, LANES>(acc, qA, qB, [](uint32_t w) { return w; }, store);
+        lin_flush<NW, LANES>(acc, qA, qB, [](uint32_t w) { return w; }, store && bd.store(0, t - 8, t - 1), store && bd.store(1, t - 8, t - 1));
         qA += QD * kWsRow;
         qB += QD * kWsRow;
         if (AMAX) fold(k - 8);
@@ -612,7 +558,8 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
     }
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
-        lin_flush<NW, LANES>(acc, qA, qB, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); }, store);
+        lin_flush<NW, LANES>(acc, qA, qB, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); },
+                             store && bd.store(0, t - (k & 7), t - 1), store && bd.store(1, t - (k & 7), t - 1));
     }
     if (AMAX) return 0;
     // H[R][Q]: slot cq of the lane that owns column Q, at the row of the last step; drift taken off
@@ -641,7 +588,8 @@ struct WideLayoutLin : UniformLayout<10, 32, true> {
     {
         static_assert(!RAW, "the linear-gap pass reads 2-bit sets");
         return dp_pass_lin<10, 32, false>(kc, gl, ref16, qb, T_end, tB, wsA, wsB, (imax(pt.Q[0], 1) - 1) % 10,
-                                          (imax(pt.Q[1], 1) - 1) % 10, nullptr, nullptr, pt.col_from);
+                                          (imax(pt.Q[1], 1) - 1) % 10, nullptr, nullptr, pt.col_from, pt.band, pt.Q[0], pt.Q[1],
+                                          pt.full[0], pt.full[1]);
     }
     __device__ static int fin_lane(int Q) { return (imax(Q, 1) - 1) / 10; }
 };
@@ -660,8 +608,7 @@ template <int C1, int C2> struct SplitLayoutLin : SplitLayout<C1, C2, true> {
                                     int T_end, int tB, uint32_t *wsA, uint32_t *wsB, const PairTile &pt)
     {
         static_assert(!RAW, "the linear-gap pass reads 2-bit sets");
-        (void)pt;
-        return dp_pass_lin_split<C1, C2>(kc, gl, ref16, qb, T_end, tB, wsA, wsB);
+        return dp_pass_lin_split<C1, C2>(kc, gl, ref16, qb, T_end, tB, wsA, wsB, pt.band, pt.full[0], pt.full[1]);
     }
     // lane and half-word of pass()'s return value that hold H[R][Q] of slot h
     __device__ static int fin_lane(int Q) { (void)Q; return kGroup - 1; }

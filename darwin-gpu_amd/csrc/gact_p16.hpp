@@ -44,30 +44,18 @@ __device__ unsigned long long g_wave_cycles[4096];
 #define GACT_SEED_WALK_TEAM 1
 #endif
 
-// timing experiments (wrong results; never in a shipped build): no traceback walk / no pointer stores
+// timing experiments (results are WRONG by design): no traceback walk / no pointer stores.  Only with -DGACT_EXPERIMENTS,
+// and gact_hip_create says so on stderr (gact_engine.hip); the experiments of rounds 2-3 that lived in the flush are in
+// the history of this file and in DESIGN.md 5.0, not here
+#ifndef GACT_EXPERIMENTS
+#undef GACT_EXP_FAKE_WALK
+#undef GACT_EXP_NO_STORE
+#endif
 #ifndef GACT_EXP_FAKE_WALK
 #define GACT_EXP_FAKE_WALK 0
 #endif
 #ifndef GACT_EXP_NO_STORE
 #define GACT_EXP_NO_STORE 0
-#endif
-#ifndef GACT_PTR_BUFFER_STORE
-#define GACT_PTR_BUFFER_STORE 0
-#endif
-#ifndef GACT_EXP_SPLIT_FLUSH
-#define GACT_EXP_SPLIT_FLUSH 0
-#endif
-#ifndef GACT_EXP_FLUSH16
-#define GACT_EXP_FLUSH16 0
-#endif
-#ifndef GACT_EXP_STORE_ONE
-#define GACT_EXP_STORE_ONE 0
-#endif
-#ifndef GACT_EXP_STORE_CONST
-#define GACT_EXP_STORE_CONST 0
-#endif
-#ifndef GACT_EXP_STORE_HOME
-#define GACT_EXP_STORE_HOME 0          // every flush block of a tile overwrites its block 0: same stores, no footprint
 #endif
 
 constexpr int kNegInf16 = -16384;
@@ -540,6 +528,8 @@ struct PairTile {
     int64_t rp0[kSlots], qp0[kSlots];
     int comp[kSlots];
     int col_from;            // first DP column (1-based) a non-first tile's walk can reach, the smaller of the two tiles'
+    int band;                // linear-gap passes: pointer words are stored within this many columns of the diagonal through (R, Q) ...
+    bool full[kSlots];       // ... unless the tile stores its whole window (gact_lin.hpp LinBand; 0: every tile does)
 };
 
 template <int C, bool RAW, int LANES = kGroup>
@@ -829,11 +819,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     // [tile A | tile B][the wave's 64 lanes] uint4 (kWsRow, gact_device.hpp), so a store instruction writes one KB
     constexpr int kWsPerTile = LANES / kGroup;
     static_assert(G::kWsWords <= kWsPerTile * Geometry<20>::kWsWords || L::kSlotsPerLane > 20, "workspace stride");
-#if GACT_EXP_STORE_HOME == 2
-    uint32_t *wsA = ws_all + (w.g * LANES) * 4;           // timing experiment: every wave of the chip on the same rows
-#else
     uint32_t *wsA = ws_all + (size_t)(w.slot / kGroupsOfWave) * (8 * (size_t)kp.ws_words) + (w.g * LANES) * 4;
-#endif
     uint32_t *wsB = wsA + 64 * 4;
 
     ChainState *st = chain_lds[group_in_block];
@@ -894,6 +880,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
             have[h] = pk.have;
             pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
             pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
+            pt.full[h] = s.full != 0;
             if (pk.have) longest = imax(longest, chain_remaining(s));
             Tend_h[h] = L::last_step(pk.R, pk.Q);
             tB_h[h] = L::first_pointer_step(pk.R, pk.Q, kp.early);
@@ -914,6 +901,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         // (a layout whose walker wants H[R][Q] from the pass delays every tile all the way: last row = last step)
         // the walk starts in column Q and stops after `early` query steps (align.cpp:205)
         pt.col_from = imax(imin(have[0] ? pt.Q[0] : 0x7fff, have[1] ? pt.Q[1] : 0x7fff) - kp.early, 0);
+        pt.band = kp.band;
         pt.shift[0] = have[0] ? (L::kEndAligned ? T_end - Tend_h[0] : imax(0, tB - tB_h[0])) : 0;
         pt.shift[1] = have[1] ? (L::kEndAligned ? T_end - Tend_h[1] : imax(0, tB - tB_h[1])) : 0;
 
@@ -953,6 +941,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
 
         // ---- traceback: lane h of the group walks slot h, all walkers of the wave in one loop
         int ref_steps = 0, query_steps = 0, nst = 0;
+        bool redo = false;               // banded pointer stores (gact_lin.hpp LinBand): the walk left the band, the tile runs again
         ScoreWalk wk;
         wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
         // (the linear-gap format is walked by a team of eight lanes per tile: the first eight lanes of the tile's half
@@ -967,6 +956,9 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
             const uint8_t *qrow = q8 + h * G::kTileMax;
             int l0, c0, k0;
             L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
+            // how far from the diagonal through (R, Q) a walk of this tile may be when it refills; -1: every block is there
+            const int band_lim = (L::kWalkFmt == 3 && (kp.band & 0xffff) > 0 && !(h ? pt.full[1] : pt.full[0]))
+                                     ? (kp.band & 0xffff) - (kTeamWalk ? kLaBandMargin : kWalkBandMargin) : -1;
             if constexpr (kTeamWalk && GACT_EXP_FAKE_WALK) {
                 // timing experiment only (results are wrong): no walk, every tile taken as a diagonal of `early` steps
                 wk.load(st[h]);
@@ -977,13 +969,13 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 wk.load(st[h]);
                 walk_chain_lin_team<L::kWalkCols, L::kWalkQuads, kWsRow, walk_span<L>()>(tb_lds[group_in_block][h], mine, Rh, Qh, l0, c0, k0, kp.early,
                                                                         rrow, 2, qrow, kp, wk, ref_steps, query_steps, nst,
-                                                                        h ? v0_h[1] : v0_h[0], h ? wsB : wsA, ws_all);
+                                                                        h ? v0_h[1] : v0_h[0], h ? wsB : wsA, ws_all, band_lim, redo);
             } else if (mine) {
                 const ChainState &s = st[h];
                 wk.load(s);
                 walk_chain<L::kWalkCols, L::kWalkFmt, L::kWalkQuads, kWsRow>(h ? wsB : wsA, tb_lds[group_in_block][h], Rh, Qh, l0, c0, k0,
                                                            kp.early, rrow, 2, qrow, s.phase, kp, wk, ref_steps,
-                                                           query_steps, nst, h ? v0_h[1] : v0_h[0], ws_all);
+                                                           query_steps, nst, h ? v0_h[1] : v0_h[0], ws_all, band_lim, &redo);
             }
         }
         GACT_STAMP(t_f);
@@ -992,9 +984,17 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         for (int h = 0; h < kSlots; h++) {
             if (have[h]) {
                 ChainState s = st[h];
-                s.n_tiles++;
-                s.cells += (int64_t)pt.R[h] * pt.Q[h];
-                chain_advance<LANES>(s, false, wk, ref_steps, query_steps, nst, h * kWalkLanes);
+                if (__shfl((int)redo, h * kWalkLanes, LANES)) {
+                    // the walk left the band its pass stored: nothing of it counts, the same tile comes again (chain_pick
+                    // finds the state it found) and stores its whole window
+                    s.full = 1;
+                    if (w.gl == 0) atomicAdd(cq.band_redos, 1);
+                } else {
+                    s.full = 0;
+                    s.n_tiles++;
+                    s.cells += (int64_t)pt.R[h] * pt.Q[h];
+                    chain_advance<LANES>(s, false, wk, ref_steps, query_steps, nst, h * kWalkLanes);
+                }
                 wave_sync();
                 if (w.gl == 0) st[h] = s;
             }
@@ -1026,7 +1026,8 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
                                                 const uint32_t (&qb)[C], const int T_end, const int tB,
                                                 uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
                                                 const int cqA, const int cqB, const int (*RQ)[2], P16Best *pb,
-                                                const int col_from = 0);
+                                                const int col_from = 0, const int band = 0, const int QA = 0, const int QB = 0,
+                                                const bool fullA = true, const bool fullB = true);
 
 // ---------------------------------------------------------------------------
 // Packed seed launch: the first tile(s) of every candidate (arg-max, pointers of the
@@ -1088,6 +1089,7 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
             pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
             pt.rp0[h] = pk.rp0; pt.qp0[h] = pk.qp0; pt.comp[h] = s.comp; pt.shift[h] = 0;
             RQ[h][0] = pk.R; RQ[h][1] = pk.Q;
+            pt.full[h] = true;
             wave_sync();
             if (w.gl == 0) st[h] = s;
             wave_sync();
@@ -1132,6 +1134,7 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
         wk.score = 0; wk.pend_gap = 0; wk.open_flag = 0; wk.have_left = 0; wk.left_first_gap = 0;
         constexpr bool kTeamWalk = LIN && GACT_SEED_WALK_TEAM;              // (see extend_p16_kernel)
         constexpr int kWalkLanes = kTeamWalk ? kGroup / kSlots : 1;
+        bool no_redo = false;                                              // (first tiles store every block: nothing to give up)
         {
             const int h = kTeamWalk ? w.gl / kWalkLanes : (w.gl & 1);
             const bool mine = (kTeamWalk || w.gl < kSlots) && !(h ? stop[1] : stop[0]);
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
                 walk_chain_lin_team<C, ((C + 1) / 2 + 3) / 4, kWsRow, 16>(tb_lds[group_in_block][h], mine, i0, j0, l0, (j0 - 1) - l0 * C,
                                                                       i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
                                                                       kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0],
-                                                                      h ? wsB : wsA, ws_all);
+                                                                      h ? wsB : wsA, ws_all, -1, no_redo);
             } else if (mine) {
                 walk_chain<C, LIN ? 3 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4, kWsRow>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
                                                   i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,

@@ -47,7 +47,7 @@ class RunStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("seed_ms", C.c_float), ("main_ms", C.c_float),
                 ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_packed16", C.c_int32),
                 ("tagged_pointers", C.c_int32), ("linear_gap", C.c_int32), ("seed_cells", C.c_int64),
-                ("raw_candidates", C.c_int32), ("reserved", C.c_int32)]
+                ("raw_candidates", C.c_int32), ("band_redos", C.c_int32)]
 
 
 class DsoftParams(C.Structure):
@@ -356,7 +356,8 @@ class Engine:
                 "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split", "packed16-wide")[st.packed16],
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
                 "tagged_pointers": bool(st.tagged_pointers), "linear_gap": bool(st.linear_gap),
-                "handed_off": st.handed_off, "seed_cells": st.seed_cells, "raw_candidates": st.raw_candidates}
+                "handed_off": st.handed_off, "seed_cells": st.seed_cells, "raw_candidates": st.raw_candidates,
+                "band_redos": st.band_redos}
 
     def measure_valu_rate(self):
         v = C.c_double()

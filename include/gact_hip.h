@@ -271,7 +271,9 @@ typedef struct {
     int32_t raw_candidates;             /* candidates the run aligned from raw bytes because one of their two reads holds a byte
                                            other than A/C/G/T (align.cpp:134), while the rest ran on the 2-bit image; 0 when no
                                            set holds such a byte, or when the whole run compared raw bytes */
-    int32_t reserved;
+    int32_t band_redos;                 /* linear-gap main launch: tiles run a second time with their whole pointer window stored,
+                                           because the traceback left the band around the diagonal the first run had stored
+                                           (exact either way; some tenths of a percent of the tiles at 15 % read error) */
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
 

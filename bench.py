@@ -73,6 +73,29 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
     return None
 
 
+def pmc_default_lookup(workload_name, candidates, cells_per_step):
+    """VALU instructions ALL kernels of one step execute, from the newest committed PMC pass of the DEFAULT command
+    (profiles/r*/pmc_default_*.json, tools/pmc_default_summary.py over scripts/gpu_pmc_default.sh: rocprofv3 --pmc
+    SQ_INSTS_VALU GRBM_GUI_ACTIVE around `bench.py --no-others`, steps in flight as in the timed region); None without one
+    for this workload and cell count."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    if candidates != "dsoft":
+        return None
+    paths = sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_default_*%s*.json" % workload_name)),
+                   key=lambda q: (os.path.basename(os.path.dirname(q)), os.path.getmtime(q)), reverse=True)
+    for path in paths:
+        try:
+            d = json.load(open(path))
+            if d["cells_per_step"] != cells_per_step:
+                continue
+            return {"source": os.path.relpath(path, here), "insts_valu_per_step": d["insts_valu_per_step"],
+                    "steps_profiled": d["steps_profiled"], "kernels": d["kernels"]}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 # Algorithmic work of the main launch, per DP cell, in lane-op slots (DESIGN.md 3.6).  One slot = one lane of one
 # wave64 VALU instruction; the kernels work on int16 pairs, two cells per slot.  Per cell PAIR the recurrence of
 # align.cpp:134-160 needs, in the cheapest formulation known for the scoring in use,
@@ -244,36 +267,41 @@ def main():
 
     def run_steps(n_steps, in_flight, record_ms=False):
         """n_steps passes over the candidate list, `in_flight` of them launched before the oldest is completed"""
-        rec = gathered = None
-        for k in range(n_steps):
-            launch(k % in_flight)
-            if k >= in_flight - 1:
-                rec, gathered = complete((k - (in_flight - 1)) % in_flight, record_ms)
-        for k in range(max(n_steps - (in_flight - 1), 0), n_steps):
-            rec, gathered = complete(k % in_flight, record_ms)
-        return rec, gathered
+        last = gdist.run_pipelined(n_steps, in_flight, launch, lambda slot: complete(slot, record_ms))
+        return last if last is not None else (None, None)
 
     run_steps(args.warmup, S)
     barrier()
     t0 = time.perf_counter()
-    rec, gathered = run_steps(args.steps, S, record_ms=(S == 1))
+    rec, gathered = run_steps(args.steps, S)
     barrier()
     dt = time.perf_counter() - t0
-    # the same steps one at a time (launched, waited for, fetched), for the per-kernel HIP-event times of the roofline
-    # and as the figure of rounds 1-2: inside the timed region kernels of consecutive steps share the machine and a
-    # kernel's own duration says nothing about it
+    # the same steps one at a time (launched, waited for, fetched), as the figure of rounds 1-2: `single_slot`
     n_single, dt_single = args.steps, dt / max(args.steps, 1)
     if S > 1:
         n_single = min(5, max(2, args.steps))
         t1 = time.perf_counter()
-        run_steps(n_single, 1, record_ms=True)
+        run_steps(n_single, 1)
         barrier()
         dt_single = (time.perf_counter() - t1) / n_single
+    single_overlapped = bool(eng.last_run_stats(0)["overlapped_seeding"]) if nf + nr else False
+    # ... and once more in the engine's plain sequence -- seed launch, then ONE main launch on the whole machine -- for the
+    # per-kernel HIP-event times of `roofline`: a kernel's own duration is the time the chip spent on it only when it runs
+    # alone (inside the timed region the kernels of S steps share the machine; and one at a time the engine seeds most of a
+    # run beside two main launches, gact_hip_run_stats.overlapped_seeding)
+    n_roof = min(4, max(2, args.steps))
+    eng.set_option("overlap_seed", 0)
+    run_steps(1, 1)
+    t2 = time.perf_counter()
+    run_steps(n_roof, 1, record_ms=True)
+    barrier()
+    dt_roof = (time.perf_counter() - t2) / n_roof
+    eng.set_option("overlap_seed", 1)
     if rec is None:          # distributed run: the engine's full records of this rank, for the cell count and the parity gate
         rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_bufs[0])
         # what rank 0 gathered of EVERY rank is what that rank's engine holds (checksums, one all_gather)
         try:
-            gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
+            rank_sums = gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
         except RuntimeError as err:
             raise SystemExit("bench.py: %s" % err)
     for k in sorted(ran - {0}):    # every slot that took a step holds the same records
@@ -294,6 +322,11 @@ def main():
     else:
         tot_tiles = my_tiles
 
+    gen_all = None
+    if use_dist:
+        g = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(g, torch.tensor([t_gen], dtype=torch.float64, device="cuda"))
+        gen_all = [round(float(x.item()), 1) for x in g]
     if rank == 0:
         gcups = tot_cells * args.steps / max_dt / 1e9
         # dominant kernel: the main launch (packed-int16 extend_p16_kernel, or the int32 extend_kernel when
@@ -337,6 +370,11 @@ def main():
             # (4.87 -> 3.78 -> 3.28 -> 3.09 slots per cell): compare rounds on valu_issue_utilisation, executed_slots_per_cell
             # and survey_24op_int32, not on frac.
             "bound": "valu",
+            # which execution mode the figures of this block describe: the main launch alone, one step at a time -- the
+            # `single_slot` leg, where a kernel's HIP-event duration is the time the chip spent on it.  `pipelined` below
+            # describes the timed region `value` is measured in.
+            "mode": "one step at a time, seed launch then one main launch (%d steps behind the timed region; "
+                    "%.3f ms per step, %.1f GCUPS)" % (n_roof, dt_roof * 1e3, my_cells / dt_roof / 1e9),
             "valu_issue_utilisation": executed["valu_issue_utilisation"] if executed else None,
             "executed_slots_per_cell": executed["slots_per_cell"] if executed else None,
             "achieved": round(achieved, 3), "peak": round(peak_slots, 3),
@@ -346,9 +384,8 @@ def main():
             "executed": executed,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": main_kernel,
-            "measured_in": ("the timed region" if S == 1 else
-                            "%d steps run one at a time right after the timed region: inside it the kernels of %d steps in flight share "
-                            "the machine, and a kernel's own HIP-event duration is not what the chip spent on it" % (n_single, S)),
+            "measured_in": "%d steps run one at a time in the plain sequence right after the timed region (see `mode`); "
+                           "`pipelined` describes the timed region itself" % n_roof,
             "kernel_ms": round(float(k_ms), 3),
             "kernel_cells": main_cells, "seed_kernel": {"packed16": "seed_p16_kernel<20>", "int32": "extend_kernel<20>"}[kernel_ms[-1]["seed_layout"]],
             "seed_kernel_ms": round(seed_ms, 3), "seed_kernel_cells": seed_cells,
@@ -361,6 +398,24 @@ def main():
                                   "peak_gcups_at_24_ops": round(peak_slots * 1e3 / OPS_PER_CELL, 1)},
             "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
             "waves_per_cu": info["waves_per_cu"],
+        }
+        # ---- the same roofline for what `value` measured: every kernel of a step (seed, main, ordering, gather) against
+        #      the wall time of a step with S steps in flight.  Algorithmic slots: the floor above over ALL cells of a step
+        #      (the seed launch's first tiles included, priced like the rest); executed slots and utilisation from the
+        #      committed PMC pass of this very command, counters summed over all kernels and divided by the steps it ran.
+        step_s = max_dt / args.steps
+        pipe_achieved = floor * my_cells / step_s / 1e12
+        pmc_d = pmc_default_lookup(args.workload, args.candidates, my_cells) if not use_dist else None
+        roofline["pipelined"] = {
+            "mode": "%d step(s) in flight: the timed region `value` is measured in" % S,
+            "ms_per_step": round(step_s * 1e3, 3), "cells_per_step": my_cells,
+            "achieved": round(pipe_achieved, 3), "peak": round(peak_slots, 3), "frac": round(pipe_achieved / peak_slots, 4),
+            "executed_slots_per_cell": round(pmc_d["insts_valu_per_step"] * 64.0 / my_cells, 3) if pmc_d else None,
+            # SIMD issue slots of the whole chip over the wall time of a step, at the nominal clock
+            "valu_issue_utilisation": round(pmc_d["insts_valu_per_step"] * float(ISSUE_CYCLES) /
+                                            (info["compute_units"] * 4 * info["clock_mhz"] * 1e6 * step_s), 4) if pmc_d else None,
+            "source": (pmc_d["source"] + " (SQ_INSTS_VALU of every kernel of %d profiled steps / steps; utilisation = that x 2 cycles / "
+                       "(1024 SIMDs x %d MHz x ms_per_step))" % (pmc_d["steps_profiled"], info["clock_mhz"])) if pmc_d else None,
         }
         out = {
             "metric": "GACT GCUPS (DP cells/s) on ~10 kb PacBio-shape reads",
@@ -382,10 +437,18 @@ def main():
             "roofline": roofline,
             # the same pass one step at a time (launch, wait, fetch, then the next): the figure of rounds 1 and 2
             "single_slot": {"value": round(my_cells * (world if use_dist else 1) / dt_single / 1e9, 2) if not use_dist else None,
-                            "ms_per_step": round(dt_single * 1e3, 3), "steps": n_single},
+                            "ms_per_step": round(dt_single * 1e3, 3), "steps": n_single,
+                            # (one at a time the engine seeds a run of this size in length order, most of it beside the main
+                            #  launch: gact_hip_run_stats.overlapped_seeding)
+                            "overlapped_seeding": single_overlapped},
         }
         if gathered is not None:
+            # what the one RCCL gather delivered: records per rank and each rank's own checksum of what it sent (compared on
+            # rank 0 with what arrived, dist.verify_gathered), the seconds every rank took to build its block
             out["config"]["gathered_records"] = int(sum(len(g) for g in gathered))
+            out["config"]["gather"] = {"ranks": world, "records_per_rank": [int(len(g)) for g in gathered],
+                                       "crc32_per_rank": rank_sums if isinstance(rank_sums, list) else None,
+                                       "gen_seconds_per_rank": gen_all}
 
         if not args.no_cpu:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr)
@@ -395,6 +458,8 @@ def main():
             eng.close()
             eng = None
             if not args.only_variants:
+                # BASELINE config 2 as the reference runs it: 8 feeder threads, each with its own slot and an eighth of the list
+                out["feeder_threads"] = feeder_config(args.workload, cat, offs, rcat, my_cf, my_cr, rec)
                 out["other_configs"] = [side_config(w, args) for w in ("pacbio50mb", "ont")]
             out["variants"] = [variant_config(v, args.workload, reads, my_cf, my_cr) for v in VARIANTS]
         print(json.dumps(out))
@@ -468,6 +533,66 @@ def reference_baseline(reads, my_cf, rf, budget_s=8.0):
             "sample": "%d forward-strand candidates of this workload (%d cells, %.1f s) through the reference's own GACT / AlignWithBT "
                       "(align.cpp, gact.cpp compiled unchanged; align.cpp:85 allocates 16.8 MB per tile); lines equal to the HIP records"
                       % (n, cells, dt)}
+
+
+def feeder_config(workload_name, cat, offs, rcat, cf, cr, want, n_threads=8, steps=6):
+    """The headline workload the way the reference drives its GPU (darwin.cpp:408-433,619-629): n_threads feeder threads
+    behind a barrier, each with its own engine slot (= GPU_storage) and an n-th of the candidates (dealt round-robin),
+    each calling run + fetch `steps` times.  The engine merges runs that arrive together into one launch (the call
+    combiner, gact_hip_run_stats.merged_callers).  Records compared with the headline's."""
+    import threading
+    import numpy as np
+    from gact_amd import engine
+    eng = engine.Engine(n_slots=n_threads)
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, offs)
+    parts = []
+    for k in range(n_threads):
+        f, r = cf[k::n_threads], cr[k::n_threads]
+        eng.candidates_upload(np.concatenate([f, r]), slot=k)
+        out = np.zeros(len(f) + len(r), dtype=engine.OVERLAP_DTYPE)
+        eng.register_output(out, slot=k)
+        parts.append((len(f), len(r), out))
+    gate = threading.Barrier(n_threads + 1)
+    errors, merged = [], [0] * n_threads
+
+    def feeder(k):
+        try:
+            nf, nr, out = parts[k]
+            eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=k)       # warm-up, all threads together
+            eng.candidates_fetch(nf + nr, slot=k, out=out)
+            gate.wait()
+            gate.wait()
+            for _ in range(steps):
+                eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=k)
+                eng.candidates_fetch(nf + nr, slot=k, out=out)
+            merged[k] = eng.last_run_stats(k)["merged_callers"]
+        except Exception as err:
+            errors.append(err)
+            try:
+                gate.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=feeder, args=(k,)) for k in range(n_threads)]
+    for t in threads:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    gate.wait()
+    for t in threads:
+        t.join()
+    dt = (time.perf_counter() - t0) / steps
+    if errors:
+        raise SystemExit("bench.py: feeder threads failed: %r" % errors[:1])
+    nf_all = len(cf)
+    for k, (nf, nr, out) in enumerate(parts):
+        if out[:nf].tobytes() != want[:nf_all][k::n_threads].tobytes() or out[nf:].tobytes() != want[nf_all:][k::n_threads].tobytes():
+            raise SystemExit("bench.py: feeder thread %d's records differ from the headline's" % k)
+    cells = int(want["cells"].sum())
+    eng.close()
+    return {"workload": workload_name + "_self_overlap", "feeder_threads": n_threads, "slots": n_threads, "steps": steps,
+            "value": round(cells / dt / 1e9, 2), "unit": "GCUPS", "ms_per_step": round(dt * 1e3, 3),
+            "callers_merged_in_last_launch": merged, "records_equal_headline": True}
 
 
 def side_config(name, args):

@@ -236,8 +236,7 @@ int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int3
     *n_reverse = (int32_t)run - *n_forward;
     const size_t n = (size_t)run;
     sl.n_cands = 0; sl.h_cands.clear(); sl.checked_key[0] = -1;
-    if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve(n * gact::kBuckets) || sl.chain_states.reserve(n) ||
-        sl.deferred.reserve(2 * n))
+    if (reserve_candidates(sl, n))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     HIP_TRY(hipMemcpyAsync(d.out_base.p, base.data(), (size_t)n_tasks * sizeof(int64_t), hipMemcpyHostToDevice, sl.stream));
     hipLaunchKernelGGL(dsoft::gather_kernel, dim3(std::min(n_tasks, 65536)), dim3(64), 0, sl.stream, d.temp.p,

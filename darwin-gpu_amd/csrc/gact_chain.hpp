@@ -39,19 +39,32 @@ struct TilePick {
     int64_t rp0, qp0;             // concat positions of the two tile slices
 };
 
+// A run's candidates [first, first + n) are forward-strand below index rc_from and reverse-complement from it on
+// (GACT_calls_for / GACT_calls_rev, darwin.cpp:227-238,266-277).  A MERGED run (several callers' lists gathered into one
+// array, gact_engine.hip) passes kCompInCand instead: every candidate carries its strand in bit 30 of query_id.
+constexpr int kCompInCand = -2;
+constexpr int kCompBit = 1 << 30;
+__device__ __forceinline__ int cand_strand(const gact_candidate &c, int cand, int rc_from, int &query_id)
+{
+    const bool tagged = rc_from == kCompInCand;
+    query_id = tagged ? (c.query_id & (kCompBit - 1)) : c.query_id;
+    return tagged ? ((c.query_id >> 30) & 1) : (cand >= rc_from ? 1 : 0);
+}
+
 // darwin.cpp:227-238 + gact.cpp:57-79
 __device__ __forceinline__ void chain_begin(ChainState &s, int cand, const gact_candidate &c,
                                             const SeqSetDev &refs, const SeqSetDev &qfwd, const SeqSetDev &qrc,
                                             int rc_from)
 {
     s.cand = cand;
-    s.comp = (cand >= rc_from) ? 1 : 0;          // darwin.cpp:279 passes rev_reads_char
+    int query_id;
+    s.comp = cand_strand(c, cand, rc_from, query_id);          // darwin.cpp:279 passes rev_reads_char
     const SeqSetDev &cq = s.comp ? qrc : qfwd;
-    s.ref_id = c.ref_id; s.query_id = c.query_id;
+    s.ref_id = c.ref_id; s.query_id = query_id;
     s.rbase = refs.offsets[c.ref_id];
-    s.qbase = cq.offsets[c.query_id];
+    s.qbase = cq.offsets[query_id];
     s.ref_len = (int)(refs.offsets[c.ref_id + 1] - s.rbase);
-    s.query_len = (int)(cq.offsets[c.query_id + 1] - s.qbase);
+    s.query_len = (int)(cq.offsets[query_id + 1] - s.qbase);
     s.ref_pos = c.ref_pos; s.query_pos = c.query_pos;
     s.rev_ref_pos = c.ref_pos; s.rev_query_pos = c.query_pos;   // gact.cpp:72-73
     s.abpos = 0; s.bbpos = 0;
@@ -648,6 +661,13 @@ struct ChainQueues {
     int *band_redos;             // tiles run a second time because their walk left the stored band (gact_lin.hpp LinBand)
     const int *list_count;       // null: the seed launch takes the candidates [first, first + n) themselves
     const int *list;             // candidate indices
+    int list_n;                  // >= 0: length of `list`, known on the host (ordered seeding); -1: *list_count
+    // Overlapped seeding (gact_engine.hip run_overlapped): a main launch that starts while a second seed launch is still
+    // filing chains into a SECOND set of queues.  Once its own set is empty a wave looks at *more_flag (written in stream
+    // order behind that seed launch), and when it is set goes on with the second set.
+    const int *more_flag;        // null: this launch has one set of queues
+    int *more_count, *more_pop;  // [kBuckets] each
+    int *more_live;
 };
 
 // next candidate of a seed launch into s (group-uniform; `leader` = the group's lane 0 does the atomic, bcast = a
@@ -657,12 +677,12 @@ __device__ __forceinline__ bool seed_pop(ChainState &s, const ChainQueues &cq, b
                                          int first_cand, int n, int rc_from, const SeqSetDev &refs, const SeqSetDev &qfwd,
                                          const SeqSetDev &qrc)
 {
-    const int total = cq.list_count ? *cq.list_count : n;
+    const int total = cq.list_n >= 0 ? cq.list_n : cq.list_count ? *cq.list_count : n;
     int idx = 0;
     if (leader) idx = atomicAdd(cq.pop_seed, 1);
     idx = bcast(idx);
     if (idx >= total) return false;
-    const int cand = cq.list_count ? cq.list[idx] : first_cand + idx;
+    const int cand = cq.list ? cq.list[idx] : first_cand + idx;
     chain_begin(s, cand, cands[cand], refs, qfwd, qrc, rc_from);
     return true;
 }

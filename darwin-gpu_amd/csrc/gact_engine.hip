@@ -10,11 +10,15 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gact_hip.h"
@@ -118,6 +122,17 @@ struct Slot {
     int *d_counter = nullptr;            // see queues()
     DevBuf<int> live;
     DevBuf<int> deferred;                // route_kernel's two candidate lists (launch_extend), n entries each
+    DevBuf<int> order;                   // ordered seeding: the run's candidates by length class, longest first (run_overlapped)
+    hipStream_t aux_stream = nullptr;    // overlapped seeding: the second seed launch and the main launch behind it
+    hipEvent_t aux_ev_a = nullptr, aux_ev_b = nullptr;
+    bool overlapped = false;             // the last run seeded while its main launch was running
+    // call combiner (Combiner below; all under its mutex)
+    std::thread::id last_thread;         // who called last for this slot, and when: is a run from it likely soon?
+    std::chrono::steady_clock::time_point last_call{};
+    bool in_flight = false;              // a run has been launched and not been fetched / waited for
+    int merged_into = -1;                // index of the merge slot the last run of this slot was part of (-1: its own launches)
+    int merged_callers = 1;              // how many callers' runs that launch carried
+    hipEvent_t ev_ready = nullptr;       // candidates of this slot are in place (recorded before a merged gather)
     int routed_raw = 0;                  // how many candidates the last run aligned from raw bytes beside the 2-bit launches
     DevBuf<gact::ChainState> chain_states;
     uint32_t *d_ws = nullptr;
@@ -181,6 +196,34 @@ struct DsoftState {
 
 }  // namespace
 
+// The call combiner (round 4).  The reference's callers are N feeder threads, each with its own GPU_storage, all
+// calling GACT_Batch at about the same time (darwin.cpp:408-433,619-629).  One persistent launch per call meant N grids
+// queueing for the CUs, each with an N-th of the candidates and no load balancing inside it: 3,957 GCUPS at 8 feeders
+// against 6,300 for one caller with the whole list.  Now a run that arrives while runs of OTHER threads are arriving is
+// merged with them into one seed + main launch on a merge slot: the callers' candidate ranges gathered into one array
+// (strand in bit 30 of query_id, kCompInCand), one set of queues, longest chains of ALL callers first; the records
+// are copied back into each caller's own array behind the launch and each caller's stream waits for that.  The first
+// arrival leads: it waits a short window for the slots whose threads called within the last few milliseconds, launches
+// for everybody, and the others return.  A caller alone (one thread, however many slots: steps in flight) never waits
+// and launches on its own slot exactly as before.
+struct RunReq {
+    int slot, first, n, rc_from, same_file;
+    int status = 0;
+    bool launched = false;
+    std::string err;
+};
+struct Combiner {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<RunReq *> pending;
+    bool leader = false;
+    bool enabled = true;              // GACT_HIP_NO_COMBINE unset
+    int window_us = 1000;             // GACT_HIP_COMBINE_US: how long the leader waits for the others at most
+    int next_merge = 0;
+    int n_merge = 0;
+    long merged_launches = 0, merged_runs = 0;
+};
+
 struct gact_hip_engine {
     gact_hip_params params;
     gact::KParams kp;
@@ -194,6 +237,7 @@ struct gact_hip_engine {
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
+    bool overlap_seed = true;   // GACT_HIP_NO_OVERLAP unset: a large run on an idle engine seeds in length order, most of it beside its main launch
     bool side_lane = true;      // GACT_HIP_NO_SIDE_LANE unset: few raw-byte candidates run beside the 2-bit launches (launch_extend)
     bool route_other = true;    // GACT_HIP_NO_ROUTING unset: raw-byte kernels only for candidates with a non-ACGT read
     bool chain_prio = true;     // main launch: longest chains first in the DP issue order too
@@ -211,7 +255,9 @@ struct gact_hip_engine {
     int blocks_per_cu = 0;
     size_t ws_words_total = 0;
     SeqSet sets[GACT_NUM_SETS];
-    std::vector<Slot> slots;
+    std::vector<Slot> slots;           // [0, n_user) the callers' slots, behind them the merge slots of the combiner
+    int n_user = 0;
+    Combiner cb;
     std::mutex upload_mu;
     int64_t sets_epoch = 0;     // bumped by every upload / derive_revcomp: range checks of older sets are void
     DsoftState dsoft;
@@ -229,13 +275,51 @@ int set_device(gact_hip_engine *e)
 int check_slot(gact_hip_engine *e, int slot)
 {
     if (!e) return fail(GACT_HIP_EINVAL, "engine is NULL");
-    if (slot < 0 || slot >= (int)e->slots.size())
-        return fail(GACT_HIP_EINVAL, "slot %d out of range [0,%d)", slot, (int)e->slots.size());
+    if (slot < 0 || slot >= e->n_user)
+        return fail(GACT_HIP_EINVAL, "slot %d out of range [0,%d)", slot, e->n_user);
     return 0;
 }
 
+// a call for `slot` from this thread, now (the combiner's guess at who is about to submit a run)
+void note_call(gact_hip_engine *e, int slot)
+{
+    if (!e->cb.enabled || e->n_user < 2) return;
+    std::lock_guard<std::mutex> lk(e->cb.mu);
+    Slot &sl = e->slots[slot];
+    sl.last_thread = std::this_thread::get_id();
+    sl.last_call = std::chrono::steady_clock::now();
+}
+
+// d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [4] / [5] candidates routed to the 2-bit / the raw-byte launches,
+// [6] tiles run twice because their walk left the stored band (gact_lin.hpp LinBand), [8..8+kBuckets) bucket_count,
+// [8+kBuckets..8+2*kBuckets) bucket_pop
+// [1] pop counter of the second seed launch, [7] "second set of queues is complete" (overlapped seeding, run_overlapped);
+// behind the ring of longest_running: the second set's bucket_count / bucket_pop, the histogram and the cursors of the
+// ordering sort
+constexpr int kMoreCount = 8 + 2 * gact::kBuckets + gact::kEpochs, kMorePop = kMoreCount + gact::kBuckets;
+constexpr int kOrderHist = kMorePop + gact::kBuckets, kOrderCursor = kOrderHist + gact::kBuckets;
+constexpr int kCounterInts = kOrderCursor + gact::kBuckets;
+
 // GACT_HIP_POISON_WS: seeded garbage over the slot's whole traceback workspace (poison_kernel)
 int poison_ws(gact_hip_engine *e, Slot &sl, uint32_t salt);
+
+// stream, events, counters and traceback workspace of a slot (merge slots: on first use)
+int init_slot(gact_hip_engine *e, Slot &sl)
+{
+    if (sl.stream) return 0;
+    if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
+        hipEventCreate(&sl.ev_mid) != hipSuccess ||
+        hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&sl.d_counter, kCounterInts * sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&sl.d_flags, sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&sl.d_ws, (e->ws_words_total + 64) * sizeof(uint32_t)) != hipSuccess)      // (+ slack)
+        return fail(GACT_HIP_ENOMEM, "slot allocation failed (workspace %zu MiB per slot)", e->ws_words_total * 4 >> 20);
+    // a fresh workspace never shows what an earlier engine of this process left in the same memory
+    if (hipMemsetAsync(sl.d_ws, 0xA5, (e->ws_words_total + 64) * sizeof(uint32_t), sl.stream) != hipSuccess)
+        return fail(GACT_HIP_EDEVICE, "workspace initialisation failed");
+    return 0;
+}
 
 // device buffers of a set for `total` bases in n_seqs sequences
 int reserve_set(SeqSet &s, int64_t total, int32_t n_seqs)
@@ -325,11 +409,6 @@ int launch_tiles(gact_hip_engine *e, Slot &sl, const SeqSet &rs, const SeqSet &q
     return 0;
 }
 
-// d_counter layout (ints): [0] pop_seed, [2..3] seed_cells (u64), [4] / [5] candidates routed to the 2-bit / the raw-byte launches,
-// [6] tiles run twice because their walk left the stored band (gact_lin.hpp LinBand), [8..8+kBuckets) bucket_count,
-// [8+kBuckets..8+2*kBuckets) bucket_pop
-constexpr int kCounterInts = 8 + 2 * gact::kBuckets + gact::kEpochs;
-
 // what a seed launch + main launch pair runs on: the slot's own stream, counters, hand-off lists and workspace, or
 // the slot's side lane.  Chain states and records are indexed by candidate and shared.
 struct Lane {
@@ -352,12 +431,33 @@ gact::ChainQueues queues(const Lane &ln, Slot &sl)
     q.bucket_count = ln.d_counter + 8;
     q.bucket_pop = ln.d_counter + 8 + gact::kBuckets;
     q.live = ln.live;
-    q.live_stride = (int)(ln.live_cap / gact::kBuckets);
+    q.live_stride = (int)(ln.live_cap / (2 * gact::kBuckets));       // (the second half: the second set of overlapped seeding)
     q.states = sl.chain_states.p;
     q.longest_now = ln.d_counter + 8 + 2 * gact::kBuckets;
     q.band_redos = ln.d_counter + 6;
     q.list_count = nullptr;
     q.list = nullptr;
+    q.list_n = -1;
+    q.more_flag = nullptr;
+    q.more_count = q.more_pop = q.more_live = nullptr;
+    return q;
+}
+
+// device arrays of a slot for a list of n candidates
+int reserve_candidates(Slot &sl, size_t n)
+{
+    return (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve(2 * n * gact::kBuckets) || sl.chain_states.reserve(n) ||
+            sl.deferred.reserve(2 * n) || sl.order.reserve(n)) ? -1 : 0;
+}
+
+// the second set of queues of a lane as a launch's own set
+gact::ChainQueues second_queues(const Lane &ln, Slot &sl)
+{
+    gact::ChainQueues q = queues(ln, sl);
+    q.pop_seed = ln.d_counter + 1;
+    q.bucket_count = ln.d_counter + kMoreCount;
+    q.bucket_pop = ln.d_counter + kMorePop;
+    q.live = ln.live + (size_t)gact::kBuckets * q.live_stride;
     return q;
 }
 
@@ -397,7 +497,7 @@ int side_lane(gact_hip_engine *e, Slot &sl, int count, int blocks, Lane *out)
         sl.side_blocks = blocks;
         HIP_TRY(hipMemsetAsync(sl.side_ws, 0xA5, (ws_words_for(e, blocks) + 64) * sizeof(uint32_t), sl.side_stream));
     }
-    if (sl.side_live.reserve((size_t)count * gact::kBuckets)) return fail(GACT_HIP_ENOMEM, "device allocation failed");
+    if (sl.side_live.reserve(2 * (size_t)count * gact::kBuckets)) return fail(GACT_HIP_ENOMEM, "device allocation failed");
     *out = Lane{sl.side_stream, sl.side_counter, sl.side_live.p, sl.side_live.cap, sl.side_ws, ws_words_for(e, sl.side_blocks), sl.side_blocks};
     return 0;
 }
@@ -419,12 +519,14 @@ int launch_big_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_fro
     return 0;
 }
 
+// strands: -1 what [first, first + n) and rc_from say; else bit 0 = forward-strand candidates present, bit 1 =
+// reverse-complement ones (merged runs: rc_from == kCompInCand, the strand travels with the candidate)
 template <int C>
-int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, int same_file)
+int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, int same_file, int strands = -1)
 {
     const SeqSet &rs = e->sets[GACT_SET_REF];
     const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
-    const bool need_f = first < rc_from, need_r = first + n > rc_from;
+    const bool need_f = strands >= 0 ? (strands & 1) != 0 : first < rc_from, need_r = strands >= 0 ? (strands & 2) != 0 : first + n > rc_from;
     // Sets that hold bytes other than A/C/G/T (N, lower case) are compared as raw bytes like align.cpp:134.  With the
     // packed kernels that is decided per CANDIDATE: the launches on the 2-bit image put off every candidate one of whose
     // two reads holds such a byte (SeqSetDev::other, from pack_kernel), and a second pair of launches on the raw bytes
@@ -440,6 +542,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     kp.prio_bases[1] = !e->chain_prio ? 0x7fffffff : static_prio ? (int32_t)std::min<int64_t>(2 * longest / 3, 0x7fffffff) : rank16;
     sl.two_phase = e->p16;
     sl.routed_raw = 0;
+    sl.overlapped = false;
     // Is another slot of this engine still running?  Then this launch shares the machine (feeder threads, steps in
     // flight) and what counts is throughput: the wide layout -- faster per chain, slower per cell, made for a launch
     // that has the CUs to itself and lasts as long as its longest chain -- is not taken on its own account.
@@ -480,6 +583,90 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                     ln.live_cap, (void *)sl.chain_states.p, sl.chain_states.cap, sizeof(gact::ChainState));
             fprintf(stderr, "[gact_hip]   ref raw %p packed %p offsets %p (%lld bases), query %p %p, rc %p %p\n", (void *)rs.d_raw, (void *)rs.d_packed,
                     (void *)rs.d_offsets, (long long)rs.total, (void *)qf.d_raw, (void *)qf.d_packed, (void *)qr.d_raw, (void *)qr.d_packed);
+        }
+        // Overlapped, ordered seeding (round 4).  One at a time a run was: seed launch (every first tile, ~2 ms on ecoli10x) ->
+        // main launch, whose longest chains -- the ones that end last -- started only then.  Here the candidates are first
+        // sorted by the length class of the chain they can make (two tiny launches), and
+        //   slot stream : seed launch A (the longest nA: as many as main launch 1 has tile slots)  ->  main launch 1, on two
+        //                 thirds of the resident blocks, popping set 1 (A's hand-offs), later set 2
+        //   aux stream  : [after A] seed launch B (the rest, on the last third of the blocks, into a SECOND set of queues)
+        //                 -> flag -> main launch 2 (that third of the blocks, set 2)
+        // Every producer / consumer pair of a set of queues is still separated by a launch boundary (or by the flag written
+        // in stream order behind seed launch B plus an acquire, extend_p16_kernel): nothing is handed over between running
+        // launches.  The two thirds / one third of the workspace go with the blocks.
+        if constexpr (C == 20) {
+            const int narrow_slots0 = e->lin_grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
+            if (e->overlap_seed && !raw && !list && !trace && !e->poison && e->seed16 && e->lin && e->split && e->wide <= 0 &&
+                !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 && count >= narrow_slots0 + narrow_slots0 / 2 &&
+                count <= 4 * narrow_slots0 &&         // (a larger run: the seed phase is a few per cent of it, and two main launches
+                                                      //  side by side cost about as much -- pacbio50mb, 334 k candidates: +1.4 %)
+                e->lin_grid_blocks >= 3) {
+                if (!sl.aux_stream) {
+                    int lo = 0, hi = 0;
+                    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                    HIP_TRY(hipStreamCreateWithPriority(&sl.aux_stream, hipStreamNonBlocking, hi));
+                    HIP_TRY(hipEventCreateWithFlags(&sl.aux_ev_a, hipEventDisableTiming));
+                    HIP_TRY(hipEventCreateWithFlags(&sl.aux_ev_b, hipEventDisableTiming));
+                }
+                const int ob = std::max(1, std::min((count + 255) / 256, 1024));
+                hipLaunchKernelGGL(gact::order_hist_kernel, dim3(ob), dim3(256), 0, ln.stream, sl.cands.p, first, count, rc_from, d_rs.offsets,
+                                   d_qf.offsets, d_qr.offsets, kp.early, ln.d_counter + kOrderHist);
+                hipLaunchKernelGGL(gact::order_scatter_kernel, dim3(ob), dim3(256), 0, ln.stream, sl.cands.p, first, count, rc_from,
+                                   d_rs.offsets, d_qf.offsets, d_qr.offsets, kp.early, ln.d_counter + kOrderHist,
+                                   ln.d_counter + kOrderCursor, sl.order.p);
+                HIP_TRY(hipGetLastError());
+                const int main1_blocks = e->lin_grid_blocks * 2 / 3, main2_blocks = e->lin_grid_blocks - main1_blocks;
+                // (seed launch B runs on a third of the machine, and until it has ended main launch 1 gets no new chains: it is
+                //  given what it can seed in a few milliseconds, two candidates per resident tile slot; a larger run seeds the
+                //  rest in launch A)
+                const int nA = std::max(std::min(count, main1_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots),
+                                        count - 2 * narrow_slots0);
+                const size_t ws_split = ws_words_for(e, main1_blocks);
+                auto seed_blocks_for = [&](int cnt, int cap) { return std::max(1, std::min(((cnt + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave) + 3) / 4, cap)); };
+                auto kseed = gact::seed_p16_kernel<20, false, true>;
+                auto kmain = gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>;
+                // seed launch A
+                gact::ChainQueues qa = queues(ln, sl);
+                qa.list = sl.order.p; qa.list_n = nA;
+                hipLaunchKernelGGL(kseed, dim3(seed_blocks_for(nA, e->seed_lin_grid_blocks)), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc,
+                                   d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file, sl.overlaps.p, qa, ln.d_ws);
+                HIP_TRY(hipGetLastError());
+                if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, ln.stream));
+                HIP_TRY(hipEventRecord(sl.aux_ev_a, ln.stream));
+                // aux stream: seed launch B into the second set, the flag, main launch 2
+                HIP_TRY(hipStreamWaitEvent(sl.aux_stream, sl.aux_ev_a, 0));
+                gact::ChainQueues qb = second_queues(ln, sl);
+                qb.list = sl.order.p + nA; qb.list_n = count - nA;
+                if (count > nA) {
+                    hipLaunchKernelGGL(kseed, dim3(seed_blocks_for(count - nA, main2_blocks)), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp,
+                                       e->kc, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file, sl.overlaps.p, qb, ln.d_ws + ws_split);
+                    HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipMemsetAsync(ln.d_counter + 7, 0xff, sizeof(int), sl.aux_stream));
+                // (both main launches take set 1 -- the longer chains, complete since seed launch A ended -- and then set 2,
+                //  open by the time main launch 2 starts)
+                gact::ChainQueues q2 = queues(ln, sl);
+                {
+                    const gact::ChainQueues s2 = second_queues(ln, sl);
+                    q2.more_flag = ln.d_counter + 7;
+                    q2.more_count = s2.bucket_count; q2.more_pop = s2.bucket_pop; q2.more_live = s2.live;
+                }
+                if (count > nA) {
+                    hipLaunchKernelGGL(kmain, dim3(main2_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
+                                       same_file, sl.overlaps.p, q2, ln.d_ws + ws_split);
+                    HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
+                // main launch 1: set 1, then set 2
+                const gact::ChainQueues q1 = q2;
+                hipLaunchKernelGGL(kmain, dim3(main1_blocks), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr,
+                                   same_file, sl.overlaps.p, q1, ln.d_ws);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
+                if (first_pass) { sl.wide = false; sl.lin = true; }
+                sl.overlapped = true;
+                return 0;
+            }
         }
         // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
         if (e->seed16) {
@@ -746,6 +933,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
     e->side_lane = getenv("GACT_HIP_NO_SIDE_LANE") == nullptr;
     e->shared_hint = getenv("GACT_HIP_NO_SHARED_HINT") == nullptr;
+    e->overlap_seed = getenv("GACT_HIP_NO_OVERLAP") == nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
     if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
     if (const char *v = getenv("GACT_HIP_POISON_WS")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
@@ -806,8 +994,11 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         // tiles = a smaller live pointer footprint)
         if (const char *v = getenv("GACT_HIP_LIN_BLOCKS")) e->lin_grid_blocks = std::max(1, std::min(atoi(v), e->lin_grid_blocks));
         int wb = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wb, gact::extend_p16_kernel<gact::WideLayoutLin, false>,
-                                                             gact::kBlockThreads, 0));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wb, gact::extend_p16_kernel<gact::WideLayoutLin, false>, gact::kBlockThreads, 0) !=
+            hipSuccess) {
+            delete e;
+            return fail(GACT_HIP_EDEVICE, "hipOccupancyMaxActiveBlocksPerMultiprocessor failed");
+        }
         e->wide_lin_grid_blocks = std::max(e->grid_blocks, wb * e->prop.multiProcessorCount);
         if ((ws_words_for(std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)) + 64) * sizeof(uint32_t) >= (1ull << 32)) {
             e->lin = false;
@@ -815,31 +1006,25 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         }
     }
     if (!e->lin) e->wide_lin_grid_blocks = e->grid_blocks;
+    if (p->max_blocks > 0) {                // a small engine (gact_hip_params.max_blocks): every persistent grid capped, the workspace with them
+        for (int *g : {&e->grid_blocks, &e->seed_grid_blocks, &e->seed_lin_grid_blocks, &e->lin_grid_blocks, &e->wide_lin_grid_blocks})
+            *g = std::max(1, std::min(*g, (int)p->max_blocks));
+    }
     e->ws_words_total = ws_words_for(std::max(e->grid_blocks, std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
     if (big) {
         // one pointer matrix per wave (1 MB at 16 columns per lane, 4 MB at 32): at most 2 GiB per slot, two blocks per CU
         const size_t per_block = (gact::kBlockThreads / 64) * (e->big_cb == 16 ? gact::BigGeom<16>::kWsBytes : gact::BigGeom<32>::kWsBytes);
         e->big_blocks = (int)std::max<size_t>(1, std::min<size_t>(2 * (size_t)e->prop.multiProcessorCount, (2ull << 30) / per_block));
+        if (p->max_blocks > 0) e->big_blocks = std::max(1, std::min(e->big_blocks, (int)p->max_blocks));
         e->ws_words_total = (size_t)e->big_blocks * per_block / sizeof(uint32_t);
     }
-    e->slots.resize(p->n_slots);
-    for (auto &sl : e->slots) {
-        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
-            hipEventCreate(&sl.ev_mid) != hipSuccess ||
-            hipMalloc((void **)&sl.d_counter, kCounterInts * sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&sl.d_flags, sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&sl.d_ws, (e->ws_words_total + 64) * sizeof(uint32_t)) != hipSuccess) {     // (+ slack)
-            gact_hip_destroy(e);
-            return fail(GACT_HIP_ENOMEM, "slot allocation failed (workspace %zu MiB per slot)",
-                        e->ws_words_total * 4 >> 20);
-        }
-        // a fresh workspace never shows what an earlier engine of this process left in the same memory
-        if (hipMemsetAsync(sl.d_ws, 0xA5, (e->ws_words_total + 64) * sizeof(uint32_t), sl.stream) != hipSuccess) {
-            gact_hip_destroy(e);
-            return fail(GACT_HIP_EDEVICE, "workspace initialisation failed");
-        }
-    }
+    e->n_user = p->n_slots;
+    e->cb.enabled = getenv("GACT_HIP_NO_COMBINE") == nullptr && !big;
+    if (const char *v = getenv("GACT_HIP_COMBINE_US")) e->cb.window_us = std::max(0, atoi(v));
+    e->cb.n_merge = (e->cb.enabled && p->n_slots > 1) ? 2 : 0;
+    e->slots.resize(p->n_slots + e->cb.n_merge);            // (never resized again: references into it stay good)
+    for (int k = 0; k < p->n_slots; k++)
+        if ((rc = init_slot(e, e->slots[k]))) { gact_hip_destroy(e); return rc; }
     *out = e;
     return 0;
 }
@@ -847,6 +1032,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
 void gact_hip_destroy(gact_hip_engine *e)
 {
     if (!e) return;
+    if (getenv("GACT_HIP_TRACE") && e->cb.merged_launches)
+        fprintf(stderr, "[gact_hip] combiner: %ld merged launches carried %ld runs\n", e->cb.merged_launches, e->cb.merged_runs);
     (void)hipSetDevice(e->params.device_id);
     for (auto &sl : e->slots) {
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -857,6 +1044,12 @@ void gact_hip_destroy(gact_hip_engine *e)
         if (sl.d_flags) (void)hipFree(sl.d_flags);
         if (sl.d_ws) (void)hipFree(sl.d_ws);
         if (sl.side_stream) (void)hipStreamSynchronize(sl.side_stream);
+        if (sl.aux_stream) {
+            (void)hipStreamSynchronize(sl.aux_stream);
+            (void)hipEventDestroy(sl.aux_ev_a); (void)hipEventDestroy(sl.aux_ev_b);
+            (void)hipStreamDestroy(sl.aux_stream);
+        }
+        sl.order.release();
         sl.side_live.release();
         if (sl.side_counter) (void)hipFree(sl.side_counter);
         if (sl.side_ws) (void)hipFree(sl.side_ws);
@@ -864,6 +1057,7 @@ void gact_hip_destroy(gact_hip_engine *e)
         if (sl.side_stream) (void)hipStreamDestroy(sl.side_stream);
         if (sl.h_records) (void)hipHostFree(sl.h_records);
         if (sl.reg_out) { (void)hipHostUnregister(sl.reg_out); (void)hipGetLastError(); }
+        if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
         if (sl.ev1) (void)hipEventDestroy(sl.ev1);
         if (sl.ev_mid) (void)hipEventDestroy(sl.ev_mid);
@@ -1004,10 +1198,11 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
     if (rc) return rc;
     if (n < 0 || (n > 0 && !cands)) return fail(GACT_HIP_EINVAL, "candidates_upload: bad arguments");
     if ((rc = set_device(e))) return rc;
+    note_call(e, slot);
     Slot &sl = e->slots[slot];
     const SeqSet &rs = e->sets[GACT_SET_REF];
     const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
-    const int32_t qn = std::max(qf.n, qr.n);
+    const int32_t qn = std::min(std::max(qf.n, qr.n), gact::kCompBit);      // (bit 30 of query_id is the strand of a merged run)
     for (int32_t k = 0; k < n; k++) {
         const gact_candidate &c = cands[k];
         if (c.ref_id < 0 || c.ref_id >= rs.n || c.query_id < 0 || c.query_id >= qn)
@@ -1019,8 +1214,7 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
         if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0)
             return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
     }
-    if (sl.cands.reserve(n) || sl.overlaps.reserve(n) || sl.live.reserve((size_t)n * gact::kBuckets) || sl.chain_states.reserve(n) ||
-        sl.deferred.reserve(2 * (size_t)n))
+    if (reserve_candidates(sl, (size_t)n))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     sl.n_cands = 0;
     sl.h_cands.assign(cands, cands + n);
@@ -1031,6 +1225,151 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
     HIP_TRY(hipStreamSynchronize(sl.stream));
     sl.n_cands = (size_t)n;
     return 0;
+}
+
+// one run on one slot's own stream, queues and workspace: seed + main launch(es) behind a reset of the counters
+static int launch_run(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, int same_file, int strands)
+{
+    int rc = 0;
+    HIP_TRY(hipMemsetAsync(sl.d_counter, 0, kCounterInts * sizeof(int), sl.stream));
+    if ((rc = poison_ws(e, sl, 0))) return rc;
+    HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
+    sl.two_phase = false;
+    sl.merged_into = -1; sl.merged_callers = 1;
+    if (n > 0) {
+        rc = e->big_cb ? launch_big_extend(e, sl, first, n, rc_from, same_file)
+           : (e->C == 20) ? launch_extend<20>(e, sl, first, n, rc_from, same_file, strands)
+                          : launch_extend<32>(e, sl, first, n, rc_from, same_file, strands);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
+    sl.timed = true;
+    return 0;
+}
+
+// the runs of `batch` (two or more, same same_file) as ONE run on a merge slot
+static int launch_merged(gact_hip_engine *e, const std::vector<RunReq *> &batch)
+{
+    Combiner &cb = e->cb;
+    const int m = e->n_user + (cb.next_merge++ % cb.n_merge);
+    Slot &ms = e->slots[m];
+    int rc = init_slot(e, ms);
+    if (rc) return rc;
+    gact::MergeSegs segs;
+    int total = 0, strands = 0;
+    segs.n_segs = (int)batch.size();
+    for (size_t k = 0; k < batch.size(); k++) {
+        const RunReq &r = *batch[k];
+        Slot &src = e->slots[r.slot];
+        segs.s[k] = gact::MergeSeg{src.cands.p, r.first, r.n, r.rc_from, total};
+        total += r.n;
+        if (r.first < r.rc_from) strands |= 1;
+        if (r.first + r.n > r.rc_from) strands |= 2;
+        // the caller's candidates are in place (an upload has waited for its copy; the device filter has not)
+        HIP_TRY(hipEventRecord(src.ev_ready, src.stream));
+        HIP_TRY(hipStreamWaitEvent(ms.stream, src.ev_ready, 0));
+    }
+    if (reserve_candidates(ms, (size_t)total)) return fail(GACT_HIP_ENOMEM, "device allocation failed (merged run of %d candidates)", total);
+    ms.n_cands = (size_t)total;
+    hipLaunchKernelGGL(gact::gather_kernel, dim3(std::max(1, std::min((total + 255) / 256, 2048))), dim3(256), 0, ms.stream, segs, ms.cands.p, total);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_run(e, ms, 0, total, gact::kCompInCand, batch[0]->same_file, strands))) return rc;
+    // every caller's records back into its own array, and its stream behind that
+    for (size_t k = 0; k < batch.size(); k++) {
+        const RunReq &r = *batch[k];
+        Slot &dst = e->slots[r.slot];
+        HIP_TRY(hipMemcpyAsync(dst.overlaps.p + r.first, ms.overlaps.p + segs.s[k].base, (size_t)r.n * sizeof(gact_overlap),
+                               hipMemcpyDeviceToDevice, ms.stream));
+    }
+    HIP_TRY(hipEventRecord(ms.ev_ready, ms.stream));
+    for (size_t k = 0; k < batch.size(); k++) {
+        Slot &dst = e->slots[batch[k]->slot];
+        HIP_TRY(hipStreamWaitEvent(dst.stream, ms.ev_ready, 0));
+        dst.merged_into = m; dst.merged_callers = (int)batch.size();
+        dst.timed = true;
+    }
+    cb.merged_launches++; cb.merged_runs += (long)batch.size();
+    return 0;
+}
+
+// A run enters here.  Whoever finds no leader becomes it: waits for the callers that are likely to follow, takes
+// everything that is pending, launches, reports.
+static int combined_submit(gact_hip_engine *e, int slot, int first, int n, int rc_from, int same_file)
+{
+    using clock = std::chrono::steady_clock;
+    Combiner &cb = e->cb;
+    RunReq req;
+    req.slot = slot; req.first = first; req.n = n; req.rc_from = rc_from; req.same_file = same_file;
+    std::unique_lock<std::mutex> lk(cb.mu);
+    {
+        Slot &sl = e->slots[slot];
+        sl.last_thread = std::this_thread::get_id();
+        sl.last_call = clock::now();
+    }
+    cb.pending.push_back(&req);
+    cb.cv.notify_all();
+    while (!req.launched) {
+        if (cb.leader) { cb.cv.wait(lk); continue; }
+        cb.leader = true;
+        // ---- collect: slots another thread called for within the last few milliseconds, with nothing in flight and
+        //      nothing pending, are about to submit (feeder threads behind their barrier, darwin.cpp:408-422)
+        const auto deadline = clock::now() + std::chrono::microseconds(cb.window_us);
+        const auto me = std::this_thread::get_id();
+        // (a thread's first run on this engine: it may be one of a group that has just been started -- every idle slot
+        //  somebody else called for counts, however long ago)
+        thread_local const gact_hip_engine *submitted_to = nullptr;
+        const bool first_run = submitted_to != e;
+        submitted_to = e;
+        for (;;) {
+            const auto now = clock::now();
+            int expected = 0;
+            for (int k = 0; k < e->n_user; k++) {
+                const Slot &o = e->slots[k];
+                bool is_pending = false;
+                for (const RunReq *r : cb.pending) is_pending |= r->slot == k;
+                if (is_pending || o.last_thread == me || o.last_thread == std::thread::id()) continue;
+                if (o.in_flight) {
+                    // a run in flight whose launch has ended: its thread is inside its fetch, or about to call it, and will
+                    // be back in a moment (the other members of the launch this thread has just fetched from)
+                    const Slot &src = o.merged_into >= 0 ? e->slots[o.merged_into] : o;
+                    const hipEvent_t ev = o.merged_into >= 0 ? src.ev_ready : src.ev1;
+                    if (!ev || hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); continue; }
+                } else if (!first_run && now - o.last_call >= std::chrono::milliseconds(3)) {
+                    continue;
+                }
+                expected++;
+            }
+            if (expected == 0 || now >= deadline || (int)cb.pending.size() >= gact::kMaxMerge) break;
+            cb.cv.wait_until(lk, std::min(deadline, now + std::chrono::microseconds(50)));
+        }
+        std::vector<RunReq *> batch;
+        batch.swap(cb.pending);
+        for (RunReq *r : batch) e->slots[r->slot].in_flight = true;
+        lk.unlock();
+        // ---- launch: runs with the same same_file together, a run that is alone on its own slot
+        (void)hipSetDevice(e->params.device_id);
+        std::vector<bool> done(batch.size(), false);
+        for (size_t a = 0; a < batch.size(); a++) {
+            if (done[a]) continue;
+            std::vector<RunReq *> group;
+            for (size_t b = a; b < batch.size() && (int)group.size() < gact::kMaxMerge; b++)
+                if (!done[b] && batch[b]->same_file == batch[a]->same_file) { group.push_back(batch[b]); done[b] = true; }
+            int rc;
+            if (group.size() == 1) {
+                RunReq &r = *group[0];
+                rc = launch_run(e, e->slots[r.slot], r.first, r.n, r.rc_from, r.same_file, -1);
+            } else {
+                rc = launch_merged(e, group);
+            }
+            for (RunReq *r : group) { r->status = rc; if (rc) r->err = g_err; }
+        }
+        lk.lock();
+        for (RunReq *r : batch) r->launched = true;
+        cb.leader = false;
+        cb.cv.notify_all();
+    }
+    if (req.status) g_err = req.err;          // (the message was the leader's thread's)
+    return req.status;
 }
 
 // candidates [first, first+n) of an uploaded list against the sets this run will read them from
@@ -1076,19 +1415,8 @@ int gact_hip_candidates_run_mixed(gact_hip_engine *e, int slot, int32_t first, i
                   (need_r && e->sets[GACT_SET_QUERY_RC].n == 0)))
         return fail(GACT_HIP_EINVAL, "candidates_run: read sets not uploaded");
     if ((rc = check_candidate_range(e, sl, first, n, rc_from))) return rc;
-    HIP_TRY(hipMemsetAsync(sl.d_counter, 0, kCounterInts * sizeof(int), sl.stream));
-    if ((rc = poison_ws(e, sl, 0))) return rc;
-    HIP_TRY(hipEventRecord(sl.ev0, sl.stream));
-    sl.two_phase = false;
-    if (n > 0) {
-        rc = e->big_cb ? launch_big_extend(e, sl, first, n, rc_from, same_file)
-           : (e->C == 20) ? launch_extend<20>(e, sl, first, n, rc_from, same_file)
-                          : launch_extend<32>(e, sl, first, n, rc_from, same_file);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipEventRecord(sl.ev1, sl.stream));
-    sl.timed = true;
-    return 0;
+    if (e->cb.enabled && e->n_user > 1 && n > 0) return combined_submit(e, slot, first, n, rc_from, same_file);
+    return launch_run(e, sl, first, n, rc_from, same_file, -1);
 }
 
 int gact_hip_candidates_run_range(gact_hip_engine *e, int slot, int32_t first, int32_t n, int complement,
@@ -1110,6 +1438,19 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
     if (n < 0 || (size_t)n > sl.n_cands || (n > 0 && !out))
         return fail(GACT_HIP_EINVAL, "candidates_fetch: bad arguments (slot %d holds %zu candidates)", slot, sl.n_cands);
     if ((rc = set_device(e))) return rc;
+    note_call(e, slot);
+    // (the slot's stream is behind whatever launch carried its last run, merged or not: the copy below waits for it)
+    struct Landed {            // the run is over when this call returns, whichever way
+        gact_hip_engine *e; int slot;
+        ~Landed()
+        {
+            if (!e->cb.enabled || e->n_user < 2) return;
+            std::lock_guard<std::mutex> lk(e->cb.mu);
+            e->slots[slot].in_flight = false;
+            e->slots[slot].last_thread = std::this_thread::get_id();
+            e->slots[slot].last_call = std::chrono::steady_clock::now();
+        }
+    } landed{e, slot};
     const size_t bytes = (size_t)n * sizeof(gact_overlap);
     if (n > 0 && sl.reg_out && (char *)out >= (char *)sl.reg_out &&
         (char *)out + bytes <= (char *)sl.reg_out + sl.reg_bytes) {
@@ -1177,6 +1518,10 @@ int gact_hip_sync(gact_hip_engine *e, int slot)
     if (rc) return rc;
     if ((rc = set_device(e))) return rc;
     HIP_TRY(hipStreamSynchronize(e->slots[slot].stream));
+    if (e->cb.enabled && e->n_user > 1) {
+        std::lock_guard<std::mutex> lk(e->cb.mu);
+        e->slots[slot].in_flight = false;
+    }
     return 0;
 }
 
@@ -1185,8 +1530,8 @@ int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms)
     int rc = check_slot(e, slot);
     if (rc) return rc;
     if (!ms) return fail(GACT_HIP_EINVAL, "ms is NULL");
-    Slot &sl = e->slots[slot];
-    if (!sl.timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
+    if (!e->slots[slot].timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
+    Slot &sl = e->slots[slot].merged_into >= 0 ? e->slots[e->slots[slot].merged_into] : e->slots[slot];
     if ((rc = set_device(e))) return rc;
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
@@ -1198,10 +1543,14 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     int rc = check_slot(e, slot);
     if (rc) return rc;
     if (!st) return fail(GACT_HIP_EINVAL, "stats is NULL");
-    Slot &sl = e->slots[slot];
-    if (!sl.timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
+    if (!e->slots[slot].timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
+    // a run that was merged with other callers' runs: the figures of that launch (the merge slot's last one)
+    const int merged_callers = e->slots[slot].merged_into >= 0 ? e->slots[slot].merged_callers : 1;
+    Slot &sl = e->slots[slot].merged_into >= 0 ? e->slots[e->slots[slot].merged_into] : e->slots[slot];
     if ((rc = set_device(e))) return rc;
     memset(st, 0, sizeof *st);
+    st->merged_callers = merged_callers;
+    st->overlapped_seeding = sl.overlapped ? 1 : 0;
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
     st->main_ms = st->total_ms;
@@ -1216,7 +1565,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
         int c[kCounterInts];
         HIP_TRY(hipMemcpy(c, sl.d_counter, sizeof c, hipMemcpyDeviceToHost));
         st->handed_off = 0;
-        for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b];
+        for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b] + c[kMoreCount + b];
         memcpy(&st->seed_cells, &c[2], sizeof(int64_t));
         st->band_redos = c[6];
         if (sl.side_used) {                 // launches beside: their share of both figures
@@ -1227,6 +1576,21 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
             st->seed_cells += sc;
         }
     }
+    return 0;
+}
+
+int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
+{
+    if (!e || !name) return fail(GACT_HIP_EINVAL, "set_option: NULL argument");
+    const std::string n(name);
+    if (n == "overlap_seed") e->overlap_seed = value != 0;
+    else if (n == "combine") {
+        std::lock_guard<std::mutex> lk(e->cb.mu);
+        e->cb.enabled = value != 0 && e->cb.n_merge > 0;
+    } else if (n == "combine_window_us") {
+        std::lock_guard<std::mutex> lk(e->cb.mu);
+        e->cb.window_us = std::max(0, (int)value);
+    } else return fail(GACT_HIP_EINVAL, "set_option: unknown option '%s'", name);
     return 0;
 }
 

@@ -339,8 +339,9 @@ __global__ void route_kernel(const gact_candidate *__restrict__ cands, int first
         const bool in = k < n;
         const int cand = first + (in ? k : 0);
         const gact_candidate c = cands[cand];
-        const int32_t *qo = cand >= rc_from ? qr_other : qf_other;
-        const bool dirty = (ref_other && ref_other[c.ref_id]) || (qo && qo[c.query_id]);
+        int query_id;
+        const int32_t *qo = cand_strand(c, cand, rc_from, query_id) ? qr_other : qf_other;
+        const bool dirty = (ref_other && ref_other[c.ref_id]) || (qo && qo[query_id]);
         // one atomic per wave and list
         const unsigned long long m1 = __ballot(in && dirty), m0 = __ballot(in && !dirty);
         int b0 = 0, b1 = 0;
@@ -352,6 +353,83 @@ __global__ void route_kernel(const gact_candidate *__restrict__ cands, int first
         b1 = __shfl(b1, 0);
         const unsigned long long below = (1ull << lane) - 1;
         if (in) lists[dirty ? n + b1 + __popcll(m1 & below) : b0 + __popcll(m0 & below)] = cand;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Merged runs (gact_engine.hip, the call combiner): the candidate ranges of up to kMaxMerge callers copied into one array,
+// each candidate's strand (index >= its caller's rc_from) moved into bit 30 of query_id (kCompInCand).
+constexpr int kMaxMerge = 32;
+struct MergeSeg { const gact_candidate *src; int first, n, rc_from, base; };
+struct MergeSegs { MergeSeg s[kMaxMerge]; int n_segs; };
+__global__ void gather_kernel(MergeSegs segs, gact_candidate *__restrict__ out, int total)
+{
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
+        int g = 0;
+        while (g + 1 < segs.n_segs && k >= segs.s[g + 1].base) g++;
+        const MergeSeg &sg = segs.s[g];
+        const int idx = sg.first + (k - sg.base);
+        gact_candidate c = sg.src[idx];
+        if (idx >= sg.rc_from) c.query_id |= kCompBit;
+        out[k] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Ordered seeding: the candidates of a run sorted by the length class of the chain they can make at most (what
+// chain_bucket files a chain under once its first tile is done: bases left of the seed hit + bases right of it, in
+// tiles), longest class first -- a counting sort in two launches.  The seed launch then takes them in that order, so
+// that the chains which decide how long the run lasts are handed to the main launch first.
+__device__ __forceinline__ int order_bucket(const gact_candidate &c, int cand, int rc_from, const int64_t *__restrict__ ref_off,
+                                            const int64_t *__restrict__ qf_off, const int64_t *__restrict__ qr_off, int early)
+{
+    int query_id;
+    const int64_t *qo = cand_strand(c, cand, rc_from, query_id) ? qr_off : qf_off;
+    const int ref_len = (int)(ref_off[c.ref_id + 1] - ref_off[c.ref_id]);
+    const int query_len = (int)(qo[query_id + 1] - qo[query_id]);
+    const int rem = imax(0, imin(c.ref_pos, c.query_pos)) + imax(0, imin(ref_len - c.ref_pos, query_len - c.query_pos));
+    return kBuckets - 1 - length_class(rem / imax(early, 1));
+}
+__global__ void order_hist_kernel(const gact_candidate *__restrict__ cands, int first, int n, int rc_from,
+                                  const int64_t *__restrict__ ref_off, const int64_t *__restrict__ qf_off,
+                                  const int64_t *__restrict__ qr_off, int early, int *__restrict__ hist)
+{
+    __shared__ int l_cnt[kBuckets];
+    if (threadIdx.x < kBuckets) l_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        atomicAdd(&l_cnt[order_bucket(cands[first + k], first + k, rc_from, ref_off, qf_off, qr_off, early)], 1);
+    __syncthreads();
+    if (threadIdx.x < kBuckets && l_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], l_cnt[threadIdx.x]);
+}
+// cursor[kBuckets] zeroed by the caller; order[0 .. n) receives candidate indices (first + k), bucket 0 (longest) first
+__global__ void order_scatter_kernel(const gact_candidate *__restrict__ cands, int first, int n, int rc_from,
+                                     const int64_t *__restrict__ ref_off, const int64_t *__restrict__ qf_off,
+                                     const int64_t *__restrict__ qr_off, int early, const int *__restrict__ hist,
+                                     int *__restrict__ cursor, int *__restrict__ order)
+{
+    __shared__ int l_scan[kBuckets], l_cnt[kBuckets], l_base[kBuckets];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < kBuckets; b++) { l_scan[b] = acc; acc += hist[b]; }
+    }
+    const int stride = gridDim.x * blockDim.x;
+    // (block-uniform trip count: the barriers inside are reached by every thread)
+    for (int k0 = blockIdx.x * blockDim.x; k0 < n; k0 += stride) {
+        if (threadIdx.x < kBuckets) l_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const int k = k0 + threadIdx.x;
+        int b = 0, rank = 0;
+        if (k < n) {
+            b = order_bucket(cands[first + k], first + k, rc_from, ref_off, qf_off, qr_off, early);
+            rank = atomicAdd(&l_cnt[b], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < kBuckets && l_cnt[threadIdx.x]) l_base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], l_cnt[threadIdx.x]);
+        __syncthreads();
+        if (k < n) order[l_scan[b] + l_base[b] + rank] = first + k;
     }
 }
 

@@ -783,7 +783,9 @@ template <class L, bool TEAM> constexpr int walk_scratch_words()
 // ---------------------------------------------------------------------------
 // Persistent main kernel: every group carries two candidates (slot A / slot B).
 // RAW: the sets hold bytes other than ACGT and are compared as raw bytes (see dp_pass_p16).
-template <class L, bool RAW>
+// TWO_SETS: the launch may go on with a second set of queues (overlapped seeding, ChainQueues::more_flag); a variant of its
+// own so that the plain launch carries none of its state through the DP loop.
+template <class L, bool RAW, bool TWO_SETS = false>
 __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
@@ -827,6 +829,11 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     wave_sync();
     bool exhausted = false;
     int my_bucket = 0;           // longest chains first (ChainQueues)
+    // the set of queues this group pops from: the launch's own, later (overlapped seeding) the second one.  (One flag per
+    // lane, the pointers are picked where they are used: the DP loop owns the register file)
+    bool second_set = false;
+    constexpr bool one_set = !TWO_SETS;              // nothing to switch to
+    int idle_polls = 0;
     __builtin_amdgcn_s_setprio(3);
 #ifdef GACT_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -852,25 +859,42 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                 if (s.phase == 2) {
                     if (exhausted) break;
                     int cand = -1;
-                    while (my_bucket < kBuckets) {
-                        // look before popping: an atomic on a class that is empty or drained is one of ~12,000
-                        // (every group comes by) serialised on one address -- 4 ms of a 55 ms launch with 32 empty classes
-                        const int cnt = cq.bucket_count[my_bucket];
-                        int idx = cnt;
-                        if (w.gl == 0 && __hip_atomic_load(&cq.bucket_pop[my_bucket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt)
-                            idx = atomicAdd(&cq.bucket_pop[my_bucket], 1);
-                        idx = __shfl(idx, 0, LANES);
-                        if (idx < cnt) {
-                            cand = cq.live[(size_t)my_bucket * cq.live_stride + idx];
-                            break;
+                    for (;;) {
+                        const int *q_count = (TWO_SETS && second_set) ? cq.more_count : cq.bucket_count;
+                        int *q_pop = (TWO_SETS && second_set) ? cq.more_pop : cq.bucket_pop;
+                        const int *q_live = (TWO_SETS && second_set) ? cq.more_live : cq.live;
+                        while (my_bucket < kBuckets) {
+                            // look before popping: an atomic on a class that is empty or drained is one of ~12,000
+                            // (every group comes by) serialised on one address -- 4 ms of a 55 ms launch with 32 empty classes
+                            const int cnt = q_count[my_bucket];
+                            int idx = cnt;
+                            if (w.gl == 0 && __hip_atomic_load(&q_pop[my_bucket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt)
+                                idx = atomicAdd(&q_pop[my_bucket], 1);
+                            idx = __shfl(idx, 0, LANES);
+                            if (idx < cnt) {
+                                cand = q_live[(size_t)my_bucket * cq.live_stride + idx];
+                                break;
+                            }
+                            my_bucket++;
                         }
-                        my_bucket++;
+                        if (cand >= 0 || second_set || one_set) break;
+                        // this launch's own queues are empty.  Overlapped seeding: a second set is being filled by a seed
+                        // launch on another stream; *more_flag is written in stream order BEHIND that launch, so once it
+                        // reads non-zero the launch has ended and its writes are in memory -- an acquire at agent scope
+                        // (this XCD's caches drop what they hold of them) and the wave goes on with that set
+                        if (__hip_atomic_load(cq.more_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        second_set = true;
+                        my_bucket = 0;
                     }
                     if (cand < 0) {
-                        exhausted = true;
+                        // (no second set yet: not exhausted, the slot stays empty for this pass)
+                        if (second_set || one_set) {
+                            exhausted = true;
 #ifdef GACT_STAMPS
-                        if (!tl_empty) tl_empty = __builtin_amdgcn_s_memrealtime();
+                            if (!tl_empty) tl_empty = __builtin_amdgcn_s_memrealtime();
 #endif
+                        }
                         break;
                     }
                     s = cq.states[cand];
@@ -891,6 +915,13 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         const bool any_here = have[0] | have[1];
         if (!__any(any_here)) {
             if (__all(exhausted && st[0].phase == 2 && st[1].phase == 2)) break;
+            if (!second_set && !one_set) {
+                // a wave with nothing to do while the second set of queues is not open yet: wait a little, but never
+                // for ever -- the launch that opens it may be waiting for this wave's registers (several engine slots
+                // at work); what is left over is taken by the main launch queued behind that seed launch
+                __builtin_amdgcn_s_sleep(127);
+                if (++idle_polls > 512) { second_set = true; exhausted = true; my_bucket = kBuckets; }
+            }
             continue;
         }
         // common end / common pointer start over the wave's 8 tiles (align_starts)

@@ -6,6 +6,20 @@ transport (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
 import numpy as np
 
 
+def run_pipelined(n_steps, in_flight, launch, complete):
+    """n_steps passes over a rank's candidates with `in_flight` of them launched before the oldest is completed: step k
+    runs on slot k % in_flight, complete(slot) delivers the output of the step that ran there (for N > 1 that is where
+    the one gather of the path sits, so every rank must complete in this same order).  Returns the last complete()."""
+    last = None
+    for k in range(n_steps):
+        launch(k % in_flight)
+        if k >= in_flight - 1:
+            last = complete((k - (in_flight - 1)) % in_flight)
+    for k in range(max(n_steps - (in_flight - 1), 0), n_steps):
+        last = complete(k % in_flight)
+    return last
+
+
 def deal(cands, rank, world):
     """rank's share of a candidate list, round-robin (chain lengths vary widely,
     contiguous ranges would not balance)"""
@@ -168,7 +182,7 @@ def verify_gathered(torch, dist, my_lines, gathered, rank, world, device):
     for r in range(world):
         if checksum_lines(gathered[r]) != int(sums[r].item()):
             raise RuntimeError("gathered records of rank %d differ from what that rank's engine holds" % r)
-    return True
+    return [int(x.item()) for x in sums]          # rank 0: every rank's checksum, as that rank computed it
 
 
 def gather_records(torch, dist, records, rank, world, device):

@@ -35,7 +35,7 @@ assert TILE_DTYPE.itemsize == 28 and OVERLAP_DTYPE.itemsize == 56
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("tile_size", "tile_overlap", "match", "mismatch", "gap_open", "gap_extend",
-                 "first_tile_score_threshold", "device_id", "n_slots", "reserved")]
+                 "first_tile_score_threshold", "device_id", "n_slots", "max_blocks")]
 
 
 class DeviceInfo(C.Structure):
@@ -47,7 +47,8 @@ class RunStats(C.Structure):
     _fields_ = [("total_ms", C.c_float), ("seed_ms", C.c_float), ("main_ms", C.c_float),
                 ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_packed16", C.c_int32),
                 ("tagged_pointers", C.c_int32), ("linear_gap", C.c_int32), ("seed_cells", C.c_int64),
-                ("raw_candidates", C.c_int32), ("band_redos", C.c_int32)]
+                ("raw_candidates", C.c_int32), ("band_redos", C.c_int32),
+                ("merged_callers", C.c_int32), ("overlapped_seeding", C.c_int32)]
 
 
 class DsoftParams(C.Structure):
@@ -179,6 +180,11 @@ def load():
     L.gact_hip_derive_revcomp.argtypes = [vp]
     L.gact_hip_register_output.argtypes = [vp, C.c_int, vp, C.c_int64]
     L.gact_hip_unregister_output.argtypes = [vp, C.c_int]
+    try:                                       # (an older build loaded through GACT_HIP_LIB_PATH for an A/B run has none)
+        L.gact_hip_set_option.argtypes = [vp, C.c_char_p, i32]
+        L.gact_hip_set_option.restype = C.c_int
+    except AttributeError:
+        pass
     for name in ("register_output", "unregister_output", "derive_revcomp", "dsoft_build", "dsoft_query", "candidates_download", "create", "get_device_info", "upload_seqs", "align_tiles", "align_tiles_inline",
                  "extend_candidates", "candidates_upload", "candidates_run", "candidates_run_range", "candidates_run_mixed",
                  "candidates_fetch", "sync", "last_kernel_ms", "last_run_stats", "format_overlap"):
@@ -194,18 +200,19 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_last_kernel_ms", "gact_hip_last_run_stats", "gact_hip_device_overlaps", "gact_hip_stream",
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
            "gact_hip_candidates_download", "gact_hip_derive_revcomp", "gact_hip_register_output",
-           "gact_hip_unregister_output")
+           "gact_hip_unregister_output", "gact_hip_set_option")
 
 
 class Engine:
     """One gact_hip_engine.  Mirrors GPU_init .. GPU_close of the reference."""
 
     def __init__(self, tile_size=320, tile_overlap=120, scoring=(1, -1, -1, -1), threshold=35,
-                 device_id=0, n_slots=1):
+                 device_id=0, n_slots=1, max_blocks=0):
         self.L = load()
         self.p = Params(tile_size, tile_overlap, scoring[0], scoring[1], scoring[2], scoring[3],
-                        threshold, device_id, n_slots, 0)
+                        threshold, device_id, n_slots, max_blocks)
         self.h = C.c_void_p()
+        self._registered = {}
         self._check(self.L.gact_hip_create(C.byref(self.p), C.byref(self.h)))
         self.tile_size = tile_size
         self.tile_overlap = tile_overlap
@@ -217,6 +224,9 @@ class Engine:
 
     def close(self):
         if self.h:
+            for slot in list(getattr(self, "_registered", {})):
+                self.L.gact_hip_unregister_output(self.h, slot)
+            self._registered = {}
             self.L.gact_hip_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -314,14 +324,21 @@ class Engine:
     def register_output(self, out, slot=0):
         """page-locks a caller-owned record array that will be fetched into repeatedly (opt-in; it must outlive the
         registration)"""
-        assert out.flags["C_CONTIGUOUS"]
+        assert out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]
         self._check(self.L.gact_hip_register_output(self.h, slot, out.ctypes.data, out.nbytes))
+        self._registered[slot] = out               # (the array must not be collected while it is page-locked)
 
     def unregister_output(self, slot=0):
         self._check(self.L.gact_hip_unregister_output(self.h, slot))
+        self._registered.pop(slot, None)
 
     def sync(self, slot=0):
         self._check(self.L.gact_hip_sync(self.h, slot))
+
+    def set_option(self, name, value):
+        """scheduling switches of a live engine: "overlap_seed", "combine", "combine_window_us" (include/gact_hip.h)"""
+        if hasattr(self.L, "gact_hip_set_option"):
+            self._check(self.L.gact_hip_set_option(self.h, name.encode(), int(value)))
 
     # ---- D-SOFT on the device
     def dsoft_build(self, params=None):
@@ -357,7 +374,7 @@ class Engine:
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
                 "tagged_pointers": bool(st.tagged_pointers), "linear_gap": bool(st.linear_gap),
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells, "raw_candidates": st.raw_candidates,
-                "band_redos": st.band_redos}
+                "band_redos": st.band_redos, "merged_callers": st.merged_callers, "overlapped_seeding": bool(st.overlapped_seeding)}
 
     def measure_valu_rate(self):
         v = C.c_double()

@@ -64,7 +64,9 @@ def dsoft_candidates(rs, threads=None):
     in the order darwin.cpp:209-288 produces them."""
     from . import engine
     drv = engine.driver_path()
-    threads = threads or min(16, os.cpu_count() or 1)
+    # (one filter per rank at N > 1: the ranks of a node share its cores, and every filter holds a 1 GiB index)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    threads = threads or max(1, min(16, (os.cpu_count() or 1) // max(local_world, 1)))
     with tempfile.TemporaryDirectory() as d:
         rs.write_fasta(os.path.join(d, "reads.fasta"))
         with open(os.path.join(d, "params.cfg"), "w") as f:

@@ -4,6 +4,8 @@
 #include "gact.h"
 #include "align.h"
 
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -82,6 +84,8 @@ typedef std::tuple<int, int, int, int, int, int, int> Key;   // tile, overlap, m
 std::mutex g_side_mu;
 std::map<Key, gact_hip_engine *> g_side;
 
+// (one tile or one candidate per call: a few blocks per launch, and a traceback workspace of that size -- 7 MB where a
+// full engine's slot holds 1.3 GB)
 gact_hip_engine *side_engine(int tile, int overlap, int match, int mismatch, int open, int ext, int thr)
 {
     const Key k(tile, overlap, match, mismatch, open, ext, thr);
@@ -92,6 +96,7 @@ gact_hip_engine *side_engine(int tile, int overlap, int match, int mismatch, int
     p.tile_size = tile; p.tile_overlap = overlap;
     p.match = match; p.mismatch = mismatch; p.gap_open = open; p.gap_extend = ext;
     p.first_tile_score_threshold = thr; p.device_id = shim_device(); p.n_slots = 1;
+    p.max_blocks = 4;
     gact_hip_engine *e = nullptr;
     SAFE(gact_hip_create(&p, &e));
     if (g_side.empty())
@@ -101,6 +106,110 @@ gact_hip_engine *side_engine(int tile, int overlap, int match, int mismatch, int
         });
     g_side[k] = e;
     return e;
+}
+
+// GACT() for the driver's own reads (darwin.cpp:240-246,279-285 pass reference_seqs[id].c_str() and its per-read copies of
+// reads_seqs / rev_reads_seqs): an engine with the three global sets resident, a slot per calling thread, no lock around
+// the call.  (Until round 4 every call took a process-wide mutex and uploaded its two reads.)
+constexpr int kGactSlots = 32;
+struct GactEngine {
+    gact_hip_engine *e = nullptr;
+    std::atomic<int> next_slot{0};
+};
+std::map<Key, GactEngine *> g_gact;
+
+GactEngine *gact_engine(int tile, int overlap, int match, int mismatch, int open, int ext, int thr)
+{
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    const Key k(tile, overlap, match, mismatch, open, ext, thr);
+    auto it = g_gact.find(k);
+    if (it != g_gact.end()) return it->second;
+    gact_hip_params p;
+    memset(&p, 0, sizeof p);
+    p.tile_size = tile; p.tile_overlap = overlap;
+    p.match = match; p.mismatch = mismatch; p.gap_open = open; p.gap_extend = ext;
+    p.first_tile_score_threshold = thr; p.device_id = shim_device(); p.n_slots = kGactSlots;
+    p.max_blocks = 4;
+    GactEngine *g = new GactEngine();
+    SAFE(gact_hip_create(&p, &g->e));
+    upload_set(g->e, GACT_SET_REF, reference_seqs);
+    upload_set(g->e, GACT_SET_QUERY, reads_seqs);
+    upload_set(g->e, GACT_SET_QUERY_RC, rev_reads_seqs);
+    if (g_gact.empty())
+        atexit([] {
+            for (auto &kv : g_gact) { gact_hip_destroy(kv.second->e); delete kv.second; }
+            g_gact.clear();
+        });
+    g_gact[k] = g;
+    return g;
+}
+
+// is [str, str + len) the driver's sequence `id` of `set`?
+bool is_resident(const std::vector<std::string> &set, int id, const char *str, int len)
+{
+    return id >= 0 && (size_t)id < set.size() && set[id].size() == (size_t)len &&
+           (set[id].data() == str || memcmp(set[id].data(), str, (size_t)len) == 0);
+}
+
+}  // namespace
+
+namespace {
+
+// GACT_HIP_PAIR_STRANDS=1 (opt-in).  darwin.cpp:429-433 calls GACT_Batch twice per feeder thread: the forward-strand
+// calls, then the reverse-complement ones.  Either call is half of the thread's work, and a launch with half the
+// candidates lasts almost as long as one with all of them (it lasts as long as its longest chain): one after the other
+// they take nearly twice the time.  With the switch set the forward call only KEEPS its calls; the reverse-complement
+// call that follows on the same GPU_storage runs both strands in one launch (gact_hip_candidates_run_mixed) and writes
+// the forward lines, then its own.  Any other call in between (or GPU_close) first runs what was kept, on its own, and
+// writes it to the ofstream it came with -- which therefore has to be alive then: that is why this is a switch and not
+// the default.  The lines are the same either way.
+struct KeptForward {
+    std::vector<gact_candidate> cands;
+    std::ofstream *fout = nullptr;
+};
+std::mutex g_kept_mu;
+std::map<std::pair<void *, int>, KeptForward> g_kept;          // by (engine, slot)
+
+bool pair_strands() { static const bool on = getenv("GACT_HIP_PAIR_STRANDS") && atoi(getenv("GACT_HIP_PAIR_STRANDS")) != 0; return on; }
+bool time_prints() { static const bool on = getenv("GACT_HIP_TIME") != nullptr; return on; }
+
+void to_candidates(const std::vector<GACT_call> &calls, int num_calls, std::vector<gact_candidate> &cands)
+{
+    const size_t base = cands.size();
+    cands.resize(base + (size_t)num_calls);
+    for (int k = 0; k < num_calls; k++) {
+        gact_candidate &c = cands[base + k];
+        c.ref_id = calls[k].ref_id; c.query_id = calls[k].query_id;
+        c.ref_pos = calls[k].ref_pos; c.query_pos = calls[k].query_pos;
+    }
+}
+
+// candidates [0, rc_from) forward, the rest reverse-complement: one run, lines to the two streams; returns ms inside the engine
+long run_and_print(gact_hip_engine *e, int slot, const std::vector<gact_candidate> &cands, int rc_from, std::ofstream &fout_f,
+                   std::ofstream &fout_r)
+{
+    const int n = (int)cands.size();
+    if (n == 0) return 0;
+    std::vector<gact_overlap> out((size_t)n);
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    SAFE(gact_hip_candidates_upload(e, slot, n, cands.data()));
+    SAFE(gact_hip_candidates_run_mixed(e, slot, 0, n, rc_from, same_file ? 1 : 0));
+    SAFE(gact_hip_candidates_fetch(e, slot, n, out.data()));
+    const auto t2 = std::chrono::high_resolution_clock::now();
+    for (int k = 0; k < n; k++)
+        if (out[k].emitted) print_overlap(k < rc_from ? fout_f : fout_r, out[k]);
+    return (long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+}
+
+// what an earlier forward call left with this (engine, slot), taken out of the table
+bool take_kept(void *engine, int slot, KeptForward &out)
+{
+    std::lock_guard<std::mutex> lk(g_kept_mu);
+    auto it = g_kept.find(std::make_pair(engine, slot));
+    if (it == g_kept.end()) return false;
+    out = std::move(it->second);
+    g_kept.erase(it);
+    return true;
 }
 
 }  // namespace
@@ -132,6 +241,10 @@ void GPU_init(int tile_size_, int tile_overlap_, int gap_open, int gap_extend, i
 void GPU_close(std::vector<GPU_storage> *s, int num_threads)
 {
     (void)num_threads;
+    for (const GPU_storage &st : *s) {                       // (GACT_HIP_PAIR_STRANDS: forward calls nobody followed up)
+        KeptForward kept;
+        if (take_kept(st.engine, st.slot, kept)) run_and_print((gact_hip_engine *)st.engine, st.slot, kept.cands, (int)kept.cands.size(), *kept.fout, *kept.fout);
+    }
     if (g_main.engine) gact_hip_destroy(g_main.engine);
     g_main.engine = nullptr;
     s->clear();
@@ -142,19 +255,37 @@ void GACT_Batch(std::vector<GACT_call> calls, int num_calls, bool complement, in
 {
     (void)offset; (void)match_score; (void)mismatch_score; (void)gap_open; (void)gap_extend;
     printf("GACT_Batch, num_calls: %d, complement: %d\n", num_calls, complement);   // gact.cpp:249
-    if (num_calls <= 0) return;
-    ensure_reads_resident();
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    long time_gpu = 0;
     gact_hip_engine *e = (gact_hip_engine *)s->engine;
-    std::vector<gact_candidate> cands(num_calls);
-    for (int k = 0; k < num_calls; k++) {
-        cands[k].ref_id = calls[k].ref_id; cands[k].query_id = calls[k].query_id;
-        cands[k].ref_pos = calls[k].ref_pos; cands[k].query_pos = calls[k].query_pos;
+    KeptForward kept;
+    const bool have_kept = pair_strands() && take_kept(s->engine, s->slot, kept);
+    if (num_calls > 0 || have_kept) ensure_reads_resident();
+    if (pair_strands() && !complement) {
+        // a forward call: what an earlier one left is run now, on its own; this one is kept for the reverse-complement call
+        if (have_kept) time_gpu += run_and_print(e, s->slot, kept.cands, (int)kept.cands.size(), *kept.fout, *kept.fout);
+        if (num_calls > 0) {
+            KeptForward k;
+            to_candidates(calls, num_calls, k.cands);
+            k.fout = &fout;
+            std::lock_guard<std::mutex> lk(g_kept_mu);
+            g_kept[std::make_pair(s->engine, s->slot)] = std::move(k);
+        }
+    } else {
+        std::vector<gact_candidate> cands;
+        int rc_from = 0x7fffffff;
+        std::ofstream *fout_f = &fout;
+        if (have_kept) { cands = std::move(kept.cands); fout_f = kept.fout; }
+        if (complement) rc_from = (int)cands.size();
+        if (num_calls > 0) to_candidates(calls, num_calls, cands);
+        if (!complement) rc_from = (int)cands.size();
+        time_gpu += run_and_print(e, s->slot, cands, rc_from, *fout_f, fout);
     }
-    std::vector<gact_overlap> out(num_calls);
-    SAFE(gact_hip_extend_candidates(e, s->slot, num_calls, cands.data(), complement ? 1 : 0, same_file ? 1 : 0,
-                                    out.data()));
-    for (int k = 0; k < num_calls; k++)
-        if (out[k].emitted) print_overlap(fout, out[k]);
+    if (time_prints()) {
+        // the reference's -D TIME line (gact.cpp:291-295,412-424,554-558): milliseconds in the host loop / in the device calls
+        const long total = (long)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count();
+        printf("time_loop: %ld ms, time_gpu: %ld ms\n", total - time_gpu, time_gpu);
+    }
 }
 
 int *Align_Batch_GPU(std::vector<std::string> ref_seqs, std::vector<std::string> query_seqs,
@@ -276,6 +407,23 @@ void GACT(char *ref_str, char *query_str, int ref_length, int query_length, int 
           int ref_pos, int query_pos, int first_tile_score_threshold_, int ref_id, int query_id, bool complement,
           int match_score, int mismatch_score, int gap_open, int gap_extend, std::ofstream &fout)
 {
+    // the driver's own reads: resident once, this thread's slot, no lock
+    if (tile_size_ <= GACT_HIP_FAST_TILE && is_resident(reference_seqs, ref_id, ref_str, ref_length) &&
+        is_resident(complement ? rev_reads_seqs : reads_seqs, query_id, query_str, query_length)) {
+        GactEngine *g = gact_engine(tile_size_, tile_overlap_, match_score, mismatch_score, gap_open, gap_extend,
+                                    first_tile_score_threshold_);
+        thread_local std::map<GactEngine *, int> my_slot;
+        auto it = my_slot.find(g);
+        if (it == my_slot.end()) it = my_slot.insert(std::make_pair(g, g->next_slot.fetch_add(1))).first;
+        if (it->second < kGactSlots) {
+            gact_candidate c;
+            c.ref_id = ref_id; c.query_id = query_id; c.ref_pos = ref_pos; c.query_pos = query_pos;
+            gact_overlap o;
+            SAFE(gact_hip_extend_candidates(g->e, it->second, 1, &c, complement ? 1 : 0, same_file ? 1 : 0, &o));
+            if (o.emitted) print_overlap(fout, o);                                       // gact.cpp:213
+            return;
+        }
+    }
     std::lock_guard<std::mutex> lk(g_side_mu);
     gact_hip_engine *e = side_engine(tile_size_, tile_overlap_, match_score, mismatch_score, gap_open, gap_extend,
                                      first_tile_score_threshold_);

@@ -69,7 +69,10 @@ typedef struct {
     int32_t first_tile_score_threshold; /* gact.cpp:107 */
     int32_t device_id;                  /* reference hard-wires 0, cuda_host.cu:195 */
     int32_t n_slots;                    /* = num_threads of GPU_init */
-    int32_t reserved;
+    int32_t max_blocks;                 /* 0: every launch may fill the device (each slot then owns a traceback workspace for that
+                                           many resident tiles, 1.3 GB at the reference's parameters); > 0: no launch of this
+                                           engine uses more blocks, and the workspaces are sized for that -- an engine that only
+                                           ever sees a handful of tiles or candidates per call (the shim's AlignWithBT / GACT) */
 } gact_hip_params;
 
 /* GPU_init: cuda_host.cu:193-237 */
@@ -274,8 +277,22 @@ typedef struct {
     int32_t band_redos;                 /* linear-gap main launch: tiles run a second time with their whole pointer window stored,
                                            because the traceback left the band around the diagonal the first run had stored
                                            (exact either way; some tenths of a percent of the tiles at 15 % read error) */
+    int32_t merged_callers;             /* how many callers' runs the launch carried: > 1 when the engine merged this run with runs
+                                           other threads submitted on other slots at about the same time (feeder threads,
+                                           darwin.cpp:619-629) into one seed + main launch; the times above are that launch's */
+    int32_t overlapped_seeding;         /* 1: the candidates were seeded in order of chain length, most of them beside the main
+                                           launch (large runs on an otherwise idle engine); seed_ms is then the first seed launch
+                                           alone and main_ms holds the rest */
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
+
+/* Scheduling switches of a live engine (none of them changes a record); unknown names are refused.
+ *   "overlap_seed"       1 (default): a large run on an idle engine seeds its candidates in order of chain length, most of them
+ *                        beside the main launch (gact_hip_run_stats.overlapped_seeding); 0: seed launch, then one main launch
+ *   "combine"            1 (default when n_slots > 1): runs that different threads submit on different slots at about the same
+ *                        time are merged into one launch (gact_hip_run_stats.merged_callers); 0: every run its own launches
+ *   "combine_window_us"  how long the first of such runs waits for the others at most (default 1000) */
+int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value);
 
 /* device address of the slot's gact_overlap array (for an RCCL gather) */
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);

@@ -33,3 +33,15 @@ def hip_lib_path():
     if not os.path.exists(engine.LIB_PATH):
         engine.build()
     return engine.LIB_PATH
+
+
+_BLOCKS = {}
+
+
+def workload_block(name):
+    """a named workload's reads and candidates (gact_amd/workload.py), built once per session: simulating the reads and
+    running the D-SOFT restatement takes seconds per block, and several files use the same ones"""
+    from gact_amd import workload
+    if name not in _BLOCKS:
+        _BLOCKS[name] = workload.make_block(name, candidates="dsoft")
+    return _BLOCKS[name]

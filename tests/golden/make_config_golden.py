@@ -1,0 +1,50 @@
+"""Golden records of BASELINE configs 2 and 5 at full size: every candidate of the workload through the ORACLE
+(oracle/gact_oracle.c, the CPU restatement pinned against the reference), one CRC-32 per record over the twelve fields the
+GPU tests compare.  tests/test_gpu_configs.py checks EVERY record of the HIP engine against these (and a strided sample
+against the oracle run live): the live oracle over all 65,766 + 14,501 candidates took 3.5 of the GPU suite's 8 minutes.
+
+    python tests/golden/make_config_golden.py [workload ...]     # ~3 + 4 minutes on 8 cores; writes config_<workload>.npz
+
+The workloads are rebuilt from their seeds (gact_amd/workload.py; candidates from the D-SOFT restatement), so the file
+also carries a checksum of the candidate list it was made for."""
+import os
+import sys
+import zlib
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (os.path.join(ROOT, "darwin-gpu_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
+
+
+def record_crcs(rec):
+    """one CRC-32 per record over FIELDS as int64"""
+    a = np.stack([rec[f].astype(np.int64) for f in FIELDS], axis=1)
+    a = np.ascontiguousarray(a)
+    return np.fromiter((zlib.crc32(row.tobytes()) for row in a), dtype=np.uint32, count=len(a))
+
+
+def main():
+    from gact_amd import workload
+    import oracle_py
+    orc = oracle_py.Oracle()
+    threads = len(os.sched_getaffinity(0))
+    for name in (sys.argv[1:] or ["ecoli10x", "ont"]):
+        blk = workload.make_block(name, candidates="dsoft")
+        cat, offs = blk.rs.concat()
+        rcat, roffs = blk.rs.concat(rc=True)
+        rf, cells_f = orc.gact_many(cat, offs, cat, offs, blk.cf, complement=False, same_file=True, n_threads=threads)
+        rr, cells_r = orc.gact_many(cat, offs, rcat, roffs, blk.cr, complement=True, same_file=True, n_threads=threads)
+        rec = np.concatenate([rf, rr])
+        out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_%s.npz" % name)
+        np.savez_compressed(out, crc=record_crcs(rec), n_forward=np.int64(len(blk.cf)), n_reverse=np.int64(len(blk.cr)),
+                            candidates_crc=np.uint32(zlib.crc32(np.concatenate([blk.cf, blk.cr]).tobytes())),
+                            cells=np.int64(rec["cells"].sum()), tiles=np.int64(rec["n_tiles"].sum()))
+        print(name, len(rec), "records,", int(rec["cells"].sum()), "cells ->", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()

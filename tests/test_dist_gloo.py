@@ -72,6 +72,82 @@ def test_two_ranks_gather_equals_single_process(world):
     assert sum(sizes) == nf + nr and max(sizes) - min(sizes) <= 2
 
 
+def _pipeline_worker(rank, world, port, q):
+    """bench.py's timed region at N > 1 with steps in flight, the engine stood in for by tagged records: every rank
+    launches step k on slot k % S and completes (= gathers) the steps in launch order; rank 0 must receive, at its k-th
+    gather, step k's records of EVERY rank."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "darwin-gpu_amd"))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gact_amd import dist as gdist
+    S, steps, n_mine = 4, 11, 50 + 7 * rank                  # ragged record counts: the gather pads
+    slots = [np.zeros(n_mine, dtype=gdist.LINE_DTYPE) for _ in range(S)]
+    gather = gdist.RecordGather(torch, dist, n_mine, gdist.LINE_BYTES, rank, world, "cpu")
+    launched, seen = [0], []
+
+    def launch(slot):
+        k = launched[0]
+        launched[0] += 1
+        slots[slot]["ref_id"] = rank
+        slots[slot]["score"] = 1000 * k + np.arange(n_mine)          # what step k "computed" on this rank
+
+    def complete(slot):
+        parts = gather(slots[slot])
+        if rank == 0:
+            got = gather.to_host(parts, gdist.LINE_DTYPE)
+            seen.append([(int(g["ref_id"][0]), int(g["score"][0]) // 1000, len(g), bool((g["score"] % 1000 == np.arange(len(g))).all()))
+                         for g in got])
+        return slot
+
+    gdist.run_pipelined(steps, S, launch, complete)
+    if rank == 0:
+        q.put(seen)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_steps_in_flight_gather_in_launch_order():
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert len(seen) == 11
+    for k, parts in enumerate(seen):
+        assert [p[0] for p in parts] == [0, 1]                       # rank r's part in place r
+        assert all(p[1] == k for p in parts), (k, parts)             # ... and it is step k's, of every rank
+        assert [p[2] for p in parts] == [50, 57] and all(p[3] for p in parts)
+
+
+def test_run_pipelined_order():
+    from gact_amd import dist as gdist
+    for S in (1, 2, 4, 6):
+        for n in (0, 1, 3, 4, 9):
+            log = []
+            gdist.run_pipelined(n, S, lambda s: log.append(("L", s)), lambda s: log.append(("C", s)))
+            assert [x for x in log if x[0] == "L"] == [("L", k % S) for k in range(n)]
+            assert [x for x in log if x[0] == "C"] == [("C", k % S) for k in range(n)]
+            # a slot is never launched again before its step has been completed
+            busy = set()
+            for kind, s_ in log:
+                if kind == "L":
+                    assert s_ not in busy
+                    busy.add(s_)
+                else:
+                    busy.remove(s_)
+
+
 def test_deal_undeal_roundtrip():
     from gact_amd import dist as gdist
     x = np.arange(23)

@@ -1,14 +1,16 @@
 """GPU parity at BASELINE.json's full sizes, every workload built exactly as bench.py builds it
 (synthetic reads of the config's shape, candidates from the D-SOFT filter at the reference's parameters):
 
-  config 2  ecoli10x    all 65,766 candidates against the oracle, every record field
+  config 2  ecoli10x    all 65,766 candidates, every record field: against the oracle's records of this very workload
+                        (tests/golden/config_ecoli10x.npz, one CRC per record, made by tests/golden/make_config_golden.py)
+                        and every 4th candidate against the oracle run live
   config 3  pacbio50mb  every 33rd candidate (> 10,000, SURVEY 8d's gate) against the oracle, and the
                         size-independent properties on the full list of 333,772
-  config 5  ont         all 14,501 candidates (chains of 200-500 sequential tiles, gact.cpp:82-195) against the
-                        oracle; the engine must pick the wide layout by itself
+  config 5  ont         all 14,501 candidates (chains of 200-500 sequential tiles, gact.cpp:82-195) the same two ways;
+                        the engine must pick the wide layout by itself
 
-The oracle side runs on the host cores of the GPU box (oracle.gact_many, contiguous candidate ranges);
-about five minutes for the three workloads together.
+The oracle side runs on the host cores of the GPU box (oracle.gact_many, contiguous candidate ranges).  Until round 4
+configs 2 and 5 ran the oracle live over every candidate (3.5 of the suite's 8 minutes); GACT_TEST_FULL_ORACLE=1 still does.
 """
 import os
 import time
@@ -34,13 +36,35 @@ def _threads():
     return n
 
 
+from conftest import workload_block
+
+
+def golden_check(w, name):
+    """every record against the oracle's record of the same candidate (CRC per record); returns how many were compared,
+    0 when the workload has no golden file"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from make_config_golden import record_crcs
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_%s.npz" % name)
+    if not os.path.exists(path):
+        return 0
+    g = np.load(path)
+    assert int(g["n_forward"]) == w.nf and int(g["n_reverse"]) == w.nr
+    assert int(g["candidates_crc"]) == zlib.crc32(w.cands.tobytes()), "the golden file was made for another candidate list"
+    got = record_crcs(w.rec)
+    bad = np.flatnonzero(got != g["crc"])
+    assert len(bad) == 0, "%d records differ from the oracle's golden records, first at candidate %d: %s" % (len(bad), bad[0], w.rec[bad[0]])
+    assert int(g["cells"]) == int(w.rec["cells"].sum()) and int(g["tiles"]) == int(w.rec["n_tiles"].sum())
+    return len(got)
+
+
 class Loaded:
     """one workload resident on the device, run once"""
 
     def __init__(self, name):
-        from gact_amd import engine, workload
+        from gact_amd import engine
         t = time.time()
-        self.blk = workload.make_block(name, candidates="dsoft")
+        self.blk = workload_block(name)
         self.cat, self.offs = self.blk.rs.concat()
         self.rcat, self.roffs = self.blk.rs.concat(rc=True)
         self.eng = engine.Engine()
@@ -90,7 +114,8 @@ def test_config2_ecoli10x_every_candidate(oracle):
     try:
         assert w.nf + w.nr == 65766 and w.stats["layout"] == "packed16-split"
         _extents_ok(w)
-        assert w.oracle_check(oracle) == 65766
+        full = bool(os.environ.get("GACT_TEST_FULL_ORACLE")) or golden_check(w, "ecoli10x") != 65766
+        assert w.oracle_check(oracle, stride=1 if full else 4) >= 65766 // 4
     finally:
         w.close()
 
@@ -103,7 +128,8 @@ def test_config5_ont_every_candidate(oracle):
         assert w.stats["layout"] == "packed16-wide"          # chosen by the engine, no environment switch
         assert w.rec["n_tiles"].max() > 400 and w.rec["n_tiles"].mean() > 150
         _extents_ok(w)
-        assert w.oracle_check(oracle) == 14501
+        full = bool(os.environ.get("GACT_TEST_FULL_ORACLE")) or golden_check(w, "ont") != 14501
+        assert w.oracle_check(oracle, stride=1 if full else 4) >= 14501 // 4
     finally:
         w.close()
 
@@ -143,6 +169,16 @@ def test_config3_pacbio50mb(oracle):
         w.close()
 
 
+def _config4_block(b):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "darwin-gpu_amd"))
+    from gact_amd import workload
+    os.environ["LOCAL_WORLD_SIZE"] = "4"                                # (four filters at once: a quarter of the cores each)
+    blk = workload.make_block("pacbio50mb", block=b, candidates="dsoft")
+    return blk.rs.reads, blk.cf, blk.cr
+
+
 def test_config4_one_rank_of_eight(oracle, capsys):
     """Config 4 (500 MB of ~10 kb PacBio-shape reads, candidate batch sharded over 8 MI355X) as far as
     one GPU can show it: the workload is built the way `bench.py --gpus 8 --workload pacbio50mb` builds it (eight
@@ -155,10 +191,9 @@ def test_config4_one_rank_of_eight(oracle, capsys):
     from gact_amd import dist as gdist, engine, synth, workload
     world = 8
     t = time.time()
-    blocks = []
-    for b in range(world):
-        blk = workload.make_block("pacbio50mb", block=b, candidates="dsoft")
-        blocks.append((blk.rs.reads, blk.cf, blk.cr))
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(4) as pool:                                # (a block takes ~4 s: simulate 5,000 reads, filter them)
+        blocks = list(pool.map(_config4_block, range(world)))
     reads, cf_all, cr_all = gdist.merge_blocks(blocks)
     offs = np.zeros(len(reads) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([len(r) for r in reads])
@@ -236,7 +271,7 @@ def test_config2_eight_feeder_slots(capsys):
     import json
     import threading
     from gact_amd import engine, workload
-    blk = workload.make_block("ecoli10x", candidates="dsoft")
+    blk = workload_block("ecoli10x")
     cat, offs = blk.rs.concat(); rcat, roffs = blk.rs.concat(rc=True)
     rows = []
     want = None
@@ -248,12 +283,14 @@ def test_config2_eight_feeder_slots(capsys):
             cf, cr = blk.cf[k::n_slots], blk.cr[k::n_slots]
             eng.candidates_upload(np.concatenate([cf, cr]), slot=k)
             parts.append((len(cf), len(cr), np.zeros(len(cf) + len(cr), dtype=engine.OVERLAP_DTYPE)))
-        steps = 4
+        steps = 6
         errors = []
+        gate = threading.Barrier(n_slots)         # the reference's threads meet at one too before they call (darwin.cpp:408-422)
 
         def feeder(k):
             try:
                 nf, nr, rec = parts[k]
+                gate.wait()
                 for _ in range(steps):
                     eng.candidates_run_mixed(nf + nr, rc_from=nf, slot=k)
                     eng.candidates_fetch(nf + nr, slot=k, out=rec)
@@ -283,7 +320,8 @@ def test_config2_eight_feeder_slots(capsys):
         else:
             assert rec.tobytes() == want.tobytes()
         rows.append({"slots": n_slots, "feeder_threads": n_slots, "ms_per_step": round(dt * 1e3, 2), "gcups": round(cells / dt / 1e9, 1),
-                     "workspace_gb": round(n_slots * 1.29, 1)})
+                     "workspace_gb": round(n_slots * 1.29, 1),
+                     "callers_merged_in_last_launch": [eng.last_run_stats(k)["merged_callers"] for k in range(n_slots)]})
         eng.close()
     line = json.dumps({"config": "2 (ecoli10x), feeder threads", "candidates": int(len(blk.cf) + len(blk.cr)), "rows": rows, "records_equal": True})
     with capsys.disabled():
@@ -292,4 +330,7 @@ def test_config2_eight_feeder_slots(capsys):
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "config2_feeder_slots.json"), "w") as f:
         f.write(line + "\n")
-    assert rows[1]["gcups"] > 0.25 * rows[0]["gcups"]         # (5,214 and 3,992 in two runs of the same build: eight grids compete)
+    # the engine merges the eight threads' runs into one launch (round 4): the threads together get what one caller with the
+    # whole list gets, less the collect window and eight record copies (3,957 against 6,354 before, eight grids competing)
+    assert all(m == 8 for m in rows[1]["callers_merged_in_last_launch"])
+    assert rows[1]["gcups"] > 0.8 * rows[0]["gcups"]

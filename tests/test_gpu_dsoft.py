@@ -134,7 +134,8 @@ def test_dsoft_device_full_workload_then_gact(oracle):
     """BASELINE configs[1] at full size: the device filter's list equals the host restatement's (what bench.py
     runs on), and a slice of it extended straight from the device array equals the oracle's GACT"""
     from gact_amd import engine, synth, workload
-    blk = workload.make_block("ecoli10x", block=0, candidates="dsoft")
+    from conftest import workload_block
+    blk = workload_block("ecoli10x")
     reads = blk.rs.reads
     eng = engine.Engine()
     cat, offs = blk.rs.concat()

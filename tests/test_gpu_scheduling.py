@@ -1,0 +1,183 @@
+"""GPU: the three scheduling changes of round 4 leave every record as it was.
+
+  * the call combiner: runs that several THREADS submit on several slots at about the same time are merged into one launch
+    (csrc/gact_engine.hip Combiner; the reference's eight feeder threads behind their barrier, darwin.cpp:408-433,619-629)
+  * ordered, overlapped seeding of a large run on an idle engine (run_overlapped: two seed launches, two main launches,
+    two sets of queues)
+  * banded pointer stores of the linear-gap main launch (csrc/gact_lin.hpp LinBand): a narrow band forces second runs
+"""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
+
+
+def _load(eng, rs):
+    from gact_amd import engine
+    cat, offs = rs.concat(); rcat, roffs = rs.concat(rc=True)
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
+
+
+def _oracle_records(oracle, rs, cf, cr):
+    cat, offs = rs.concat(); rcat, roffs = rs.concat(rc=True)
+    wf, _ = oracle.gact_many(cat, offs, cat, offs, cf, complement=False, same_file=True, n_threads=8)
+    wr, _ = oracle.gact_many(cat, offs, rcat, roffs, cr, complement=True, same_file=True, n_threads=8)
+    return np.concatenate([wf, wr])
+
+
+def _same(got, want):
+    for f in FIELDS:
+        assert np.array_equal(got[f], want[f]), f
+
+
+@pytest.mark.parametrize("dirty", [False, True], ids=["clean", "reads-with-N"])
+def test_runs_of_several_threads_are_merged_and_keep_their_records(oracle, dirty):
+    """six threads, six slots, six DIFFERENT lists (sizes, strand mixes, one forward-only, one a sub-range of its upload):
+    merged into one launch they give what the oracle gives for each list"""
+    from gact_amd import engine, synth
+    rs = synth.simulate_reads(90000, n_reads=70, seed=31, mean_len=6000, sd_len=1500, min_len=1200, max_len=10000)
+    if dirty:
+        for k in (5, 22, 41):
+            r = rs.reads[k]
+            r[300:330] = ord("N")
+            r[900:960] = np.frombuffer(bytes(r[900:960]).lower(), dtype=np.uint8)
+    cf, cr = synth.synth_candidates(rs, seed=32, min_overlap=300, false_frac=0.15)
+    want_all = _oracle_records(oracle, rs, cf, cr)
+    T = 6
+    eng = engine.Engine(n_slots=T)
+    _load(eng, rs)
+    lists = []
+    for k in range(T):
+        f, r = cf[k::T], cr[k::T]
+        if k == 1:
+            r = r[:0]                                        # forward strand only
+        if k == 2:
+            f = f[:0]                                        # reverse-complement only
+        lists.append((f, r, np.concatenate([want_all[:len(cf)][k::T][:len(f)], want_all[len(cf):][k::T][:len(r)]])))
+        eng.candidates_upload(np.concatenate([f, r]), slot=k)
+    gate = threading.Barrier(T)
+    got, merged, errors = [None] * T, [0] * T, []
+
+    def feeder(k):
+        try:
+            f, r, _ = lists[k]
+            n = len(f) + len(r)
+            for rep in range(3):
+                gate.wait()
+                if k == 4:                                   # a sub-range of the uploaded list: records [5, n) only
+                    eng.candidates_run_mixed(n - 5, rc_from=len(f), first=5, slot=k)
+                else:
+                    eng.candidates_run_mixed(n, rc_from=len(f), slot=k)
+                got[k] = eng.candidates_fetch(n, slot=k).copy()
+                merged[k] = max(merged[k], eng.last_run_stats(k)["merged_callers"])
+        except Exception as err:
+            errors.append(err)
+            gate.abort()
+
+    threads = [threading.Thread(target=feeder, args=(k,)) for k in range(T)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert max(merged) >= 2, merged                          # (behind a barrier all six normally end up in one launch)
+    for k in range(T):
+        f, r, want = lists[k]
+        lo = 5 if k == 4 else 0
+        _same(got[k][lo:], want[lo:])
+    if dirty:
+        assert eng.last_run_stats(0)["raw_candidates"] > 0
+    # the same with the combiner switched off: every run its own launches
+    eng.set_option("combine", 0)
+    merged = [0] * T
+    threads = [threading.Thread(target=feeder, args=(k,)) for k in range(T)]
+    gate.reset()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors and max(merged) == 1
+    for k in range(T):
+        lo = 5 if k == 4 else 0
+        _same(got[k][lo:], lists[k][2][lo:])
+    eng.close()
+
+
+def test_one_thread_with_several_slots_is_never_merged():
+    """steps in flight from one thread (bench.py): no waiting, no merging"""
+    from gact_amd import engine, synth
+    rs = synth.simulate_reads(40000, n_reads=30, seed=41, mean_len=5000, sd_len=1000, min_len=1200, max_len=8000)
+    cf, cr = synth.synth_candidates(rs, seed=42, min_overlap=300)
+    cands = np.concatenate([cf, cr])
+    eng = engine.Engine(n_slots=3)
+    _load(eng, rs)
+    for k in range(3):
+        eng.candidates_upload(cands, slot=k)
+    for k in range(3):
+        eng.candidates_run_mixed(len(cands), rc_from=len(cf), slot=k)
+    recs = [eng.candidates_fetch(len(cands), slot=k).copy() for k in range(3)]
+    assert all(eng.last_run_stats(k)["merged_callers"] == 1 for k in range(3))
+    assert recs[1].tobytes() == recs[0].tobytes() == recs[2].tobytes()
+    eng.close()
+
+
+def test_overlapped_seeding_equals_the_plain_sequence():
+    """ecoli10x (65,766 candidates: large enough for the engine to seed in length order beside its main launch): the same
+    records with the switch off, and run after run"""
+    from conftest import workload_block
+    from gact_amd import engine
+    blk = workload_block("ecoli10x")
+    eng = engine.Engine()
+    _load(eng, blk.rs)
+    cands = np.concatenate([blk.cf, blk.cr])
+    nf = len(blk.cf)
+    eng.candidates_upload(cands)
+    recs = []
+    for rep in range(3):
+        eng.candidates_run_mixed(len(cands), rc_from=nf)
+        recs.append(eng.candidates_fetch(len(cands)).copy())
+        st = eng.last_run_stats()
+        assert st["overlapped_seeding"] and st["handed_off"] > 60000
+    eng.set_option("overlap_seed", 0)
+    eng.candidates_run_mixed(len(cands), rc_from=nf)
+    plain = eng.candidates_fetch(len(cands)).copy()
+    assert not eng.last_run_stats()["overlapped_seeding"]
+    for r in recs:
+        assert r.tobytes() == plain.tobytes()
+    # a range of the list (still large enough)
+    eng.set_option("overlap_seed", 1)
+    eng.candidates_run_mixed(len(cands) - 100, rc_from=nf, first=100)
+    part = eng.candidates_fetch(len(cands))
+    assert eng.last_run_stats()["overlapped_seeding"]
+    assert part[100:].tobytes() == plain[100:].tobytes()
+    eng.close()
+
+
+@pytest.mark.parametrize("band", [24, 0])
+def test_a_narrow_band_runs_tiles_again_and_changes_nothing(monkeypatch, oracle, band):
+    """GACT_HIP_BAND=24: walks leave the stored band in a per cent or two of the tiles, which are run again with their whole
+    window stored; 0: no band at all.  Records against the oracle, both layouts of the linear-gap main launch."""
+    from gact_amd import engine, synth
+    monkeypatch.setenv("GACT_HIP_BAND", str(band))
+    rs = synth.simulate_reads(150000, n_reads=110, seed=51, mean_len=8000, sd_len=2500, min_len=1500, max_len=15000)
+    cf, cr = synth.synth_candidates(rs, seed=52, min_overlap=400, false_frac=0.1)
+    want = _oracle_records(oracle, rs, cf, cr)
+    cands = np.concatenate([cf, cr])
+    for force in ("GACT_HIP_NO_WIDE", "GACT_HIP_FORCE_WIDE"):
+        monkeypatch.delenv("GACT_HIP_NO_WIDE", raising=False)
+        monkeypatch.delenv("GACT_HIP_FORCE_WIDE", raising=False)
+        monkeypatch.setenv(force, "1")
+        eng = engine.Engine()
+        _load(eng, rs)
+        eng.candidates_upload(cands)
+        eng.candidates_run_mixed(len(cands), rc_from=len(cf))
+        got = eng.candidates_fetch(len(cands)).copy()
+        st = eng.last_run_stats()
+        assert st["linear_gap"] and st["layout"] == ("packed16-split" if force == "GACT_HIP_NO_WIDE" else "packed16-wide")
+        assert (st["band_redos"] > 0) == (band == 24), st
+        _same(got, want)
+        eng.close()

@@ -121,6 +121,8 @@ def main_kernel_name(st):
     if st.get("linear_gap"):            # linear gap scoring: the drifted pass (gact_lin.hpp)
         name = {"extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayoutLin<7,13>>",
                 "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutLin>"}[name]
+    elif st.get("affine_drift"):        # the drifted affine pass (gact_aff.hpp), split layout
+        name = "extend_p16_kernel<SplitLayoutAff<7,13>>"
     elif st["tagged_pointers"]:         # pointer phase on tagged scores: the layouts' TAG variants
         name = {"extend_p16_kernel<UniformLayout<20>>": "extend_p16_kernel<UniformLayout<20,16,true>>",
                 "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
@@ -722,8 +724,8 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
                 "raw_byte_candidates": int(st["raw_candidates"]),
                 "tiles": int(rec["n_tiles"].sum()), "cells_per_step": cells,
                 # (a launch made while another slot is running takes the layout with the better throughput)
-                "kernel_layout": flight["layout"] + ("-lin" if flight["linear_gap"] else ""),
-                "single_slot_kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else ""),
+                "kernel_layout": flight["layout"] + ("-lin" if flight["linear_gap"] else "-aff" if flight.get("affine_drift") else ""),
+                "single_slot_kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else "-aff" if st.get("affine_drift") else ""),
                 "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
                 "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
                 "parity": {"checked_candidates": int(checked), "bit_exact": True}})

@@ -524,6 +524,14 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         if (redo) *redo = rd;
         return;
     }
+    // FMT 4 (the drifted affine pass, gact_aff.hpp): FMT 2's word layout and op numbering (3 MATCH 2 INSERT 1 DELETE), but
+    //   * the two flags come as ONE code, (I'' + D'') & 3 of the pass: 2 = both gaps open here, 0 = the insertion only,
+    //     1 = the deletion only, 3 = neither;
+    //   * ZERO is not encoded (H == 0 reads as MATCH): the walker carries v, the score of the cell it stands on in the
+    //     matrix its state names -- v0 = H[R][Q] from the pass; a MATCH column takes its substitution score off, a gap
+    //     column gap_open where its cell's flag says the gap was opened there, gap_extend where not (align.cpp:149-156) --
+    //     and after a diagonal move v is H of the cell entered: ZERO iff 0 (align.cpp:166-168), exactly as walk_chain_lin.
+    constexpr bool AFF = FMT == 4;
     constexpr uint32_t kMagic = (65536u + CW - 1) / CW;         // p / CW == (p * kMagic) >> 16 for p < 6000
     const bool left = phase == 0;
     const int p0 = l0 * CW + c0, kA = k0 - l0;
@@ -532,6 +540,8 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     const uint8_t *qa = qrow + (Q - 1);
     int nis = 0, njs = 0;                                       // minus the ref / query steps taken
     int n_ext = 0, n_open = 0, n_eq = 0, n_m = 0;
+    int v = v0;
+    bool rd = false;
     uint32_t cur = 0, fl = 0;                                   // state (op-code numbering), flags of the current cell
     TbRegion<CW> rg;
     int off0 = 0, off1 = 0;                                     // byte offsets inside the region cache
@@ -552,7 +562,7 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
-        } else if (FMT == 2) {                                   // taken as it is: the walk runs on this numbering
+        } else if (FMT == 2 || AFF) {                            // taken as it is: the walk runs on this numbering
             const uint32_t v = w >> ((~(uint32_t)k & 7u) * 2u);
             code = v & 3u;
             flags = (v >> 16) & 3u;
@@ -567,11 +577,12 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
     if (R >= 1 && Q >= 1 && early > 0) {
         refill(l0, c0, k0);
         fetch(l0, c0, k0, cur, fl);
+        if (AFF && v == 0) cur = 0;                              // H[R][Q] == 0: ZERO at the start cell
     }
     // state numbering of the walk: FMT 0 / 1 words are turned into the packed kernel's op codes (1 MATCH 2 INSERT
     // 3 DELETE, flag set = the gap goes on); FMT 2 words carry align.h:23 numbering (3 MATCH 2 INSERT 1 DELETE) and
     // flags that say the opposite (set = the gap was opened here), and the walk uses them as they are
-    constexpr uint32_t kM = FMT == 2 ? 3u : 1u, kI = 2u, kD = FMT == 2 ? 1u : 3u;
+    constexpr uint32_t kM = (FMT == 2 || AFF) ? 3u : 1u, kI = 2u, kD = (FMT == 2 || AFF) ? 1u : 3u;
     if (left && !wk.have_left && cur != 0) { wk.have_left = 1; wk.left_first_gap = cur != kM; }
     // conditions live as lane masks on the scalar unit; a counter takes one as the carry of a single VALU op
     const uint64_t left_m = lanes(left);
@@ -588,18 +599,32 @@ __device__ __forceinline__ void walk_chain(const uint32_t *ws, uint32_t *scratch
         // ---- move (align.cpp:210-229): INSERT / DELETE stay unless their flag says the gap was opened here
         nis = sub_lane_bit(nis, lanes(cur != kD));
         njs = sub_lane_bit(njs, lanes(cur != kI));
-        const uint32_t forced = FMT == 2 ? ((fl & cur) ? kM : cur) : ((fl & (4u - cur)) ? cur : kM);
+        uint32_t forced;
+        if (AFF) {
+            // the gap of the current cell was opened here: INSERT 2 and code 2 or 0, DELETE 1 and code 2 or 1
+            const bool opened = cur == kI ? !(fl & 1u) : (((fl + 1u) & 2u) != 0);
+            forced = opened ? kM : cur;
+            const int sub = ((eq >> (threadIdx.x & 63)) & 1) ? kp.match : kp.mismatch;
+            v -= cur == kM ? sub : (opened ? kp.open : kp.ext);
+        } else {
+            forced = FMT == 2 ? ((fl & cur) ? kM : cur) : ((fl & (4u - cur)) ? cur : kM);
+        }
         // (a walker that is about to stop may have left the tile: keep its addresses inside the stored window)
         const int p = imax(p0 + njs, 0);
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
         const int c = p + __mul24(l, -CW);
         const int k = imax(kA + l + nis, 0);
-        if ((it & 7) == 7) refill(l, c, k);
+        if ((it & 7) == 7) {
+            refill(l, c, k);
+            // banded stores (gact_lin.hpp LinBand), as in walk_chain_lin
+            rd = rd | ((band_lim >= 0) & ((unsigned)(nis - njs + band_lim) > (unsigned)(2 * band_lim)));
+        }
         uint32_t code;
         fetch(l, c, k, code, fl);
-        const uint32_t nxt = cur == kM ? code : forced;
-        cur = (nis <= nlim_i || njs <= nlim_j) ? 0u : nxt;       // align.cpp:205, borders :101-107
+        const uint32_t nxt = cur == kM ? ((AFF && v == 0) ? 0u : code) : forced;
+        cur = (nis <= nlim_i || njs <= nlim_j || rd) ? 0u : nxt;       // align.cpp:205, borders :101-107
     }
+    if (redo) *redo = rd;
     ref_steps = -nis; query_steps = -njs;
     nst = -nis - njs - n_m;
     wk.score += n_ext * kp.ext + n_open * kp.open + n_eq * kp.match + (n_m - n_eq) * kp.mismatch;

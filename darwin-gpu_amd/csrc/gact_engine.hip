@@ -26,6 +26,7 @@
 #include "gact_p16.hpp"
 #include "gact_p16s.hpp"
 #include "gact_lin.hpp"
+#include "gact_aff.hpp"
 #include "gact_big.hpp"
 #include "dsoft_device.hpp"
 
@@ -109,7 +110,7 @@ template <class T> struct DevBuf {
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
-    bool timed = false, two_phase = false, wide = false, lin = false;
+    bool timed = false, two_phase = false, wide = false, lin = false, aff = false;
     DevBuf<gact_tile> tiles;
     DevBuf<gact_tile_result> results;
     DevBuf<uint8_t> states;
@@ -234,6 +235,7 @@ struct gact_hip_engine {
     bool split = false;         // ... in its split (two-region) layout: tile <= 320 and early <= 208
     bool tagged = false;        // the packed main launch runs its pointer phase on tagged scores (any layout)
     bool lin = false;           // linear gaps (open == extend == mismatch): the drifted pass of gact_lin.hpp on 2-bit sets
+    bool aff = false;           // any other scoring that fits: the drifted affine pass of gact_aff.hpp (split main launch, 2-bit sets)
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
@@ -248,6 +250,7 @@ struct gact_hip_engine {
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
     int seed_lin_grid_blocks = 0;       // ... of its linear-gap form (3)
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
+    int aff_grid_blocks = 0;    // ... of the drifted affine split launch (two blocks per CU)
     int wide_lin_grid_blocks = 0;       // ... of the linear-gap wide launch
     gact::P16Consts kc;
     hipDeviceProp_t prop;
@@ -699,9 +702,12 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         using gact::extend_p16_kernel;
         const bool tg = e->tagged;
         const bool lin = e->lin && !raw && (wide || e->split);
-        if (first_pass) { sl.wide = wide; sl.lin = lin; }
+        const bool aff = e->aff && !raw && !wide && C == 20;
+        if (first_pass) { sl.wide = wide; sl.lin = lin; sl.aff = aff; }
         auto km = lin ? (wide ? extend_p16_kernel<gact::WideLayoutLin, false>
                               : extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>)
+                : aff ? (e->params.mismatch < e->params.gap_extend ? extend_p16_kernel<gact::SplitLayoutAff<7, 13, true>, false>
+                                                                   : extend_p16_kernel<gact::SplitLayoutAff<7, 13, false>, false>)
                 : wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
                              : (raw ? extend_p16_kernel<gact::WideLayout, true> : extend_p16_kernel<gact::WideLayout, false>))
                 : e->split ? (tg ? (raw ? extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
@@ -722,10 +728,12 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // takes two blocks per CU of the three that fit -- the next launch's blocks get in sooner, a third less workspace is live
         const int lin_cap = (shared_machine && ln.stream == sl.stream) ? std::max(1, e->lin_grid_blocks * 2 / 3) : e->lin_grid_blocks;
         const int lin_blocks = grid((groups_needed + 3) / 4, lin_cap);
-        hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks)), dim3(gact::kBlockThreads), 0, ln.stream, kp,
+        const int aff_cap = e->aff_grid_blocks;
+        const int main_blocks_now = aff ? grid((groups_needed + 3) / 4, aff_cap) : main_blocks;
+        hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks_now)), dim3(gact::kBlockThreads), 0, ln.stream, kp,
                            e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws);
         HIP_TRY(hipGetLastError());
-        return traced(ln, raw ? "main launch (raw bytes)" : "main launch (2-bit)", wide ? wide_blocks : (lin ? lin_blocks : main_blocks), count);
+        return traced(ln, raw ? "main launch (raw bytes)" : "main launch (2-bit)", wide ? wide_blocks : (lin ? lin_blocks : main_blocks_now), count);
     };
 
     const Lane own = main_lane(e, sl);
@@ -928,6 +936,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
                 getenv("GACT_HIP_NO_TAGGED") == nullptr;
     e->lin = e->tagged && gact::p16_lin_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
              getenv("GACT_HIP_NO_LIN") == nullptr;
+    e->aff = e->tagged && e->split && !e->lin && gact::p16_aff_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
+             getenv("GACT_HIP_NO_AFF") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
@@ -969,6 +979,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->kc.dsub4 = (uint32_t)(4 * (p->match - p->mismatch)) << 24; e->kc.floor4 = gact::pk2(-6000);
     e->kc.next = gact::pk2(-p->gap_extend); e->kc.next4 = gact::pk2(-4 * p->gap_extend);
     e->kc.ext4 = gact::pk2(4 * p->gap_extend);
+    e->kc.s_mismatch = p->mismatch; e->kc.s_open = p->gap_open; e->kc.s_ext = p->gap_extend;
 
     rc = (e->C == 20) ? occupancy_blocks<20>(&e->blocks_per_cu) : occupancy_blocks<32>(&e->blocks_per_cu);
     if (rc) { delete e; return rc; }
@@ -1006,11 +1017,21 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         }
     }
     if (!e->lin) e->wide_lin_grid_blocks = e->grid_blocks;
+    e->aff_grid_blocks = e->grid_blocks;
+    if (e->aff) {
+        int ab = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&ab, gact::extend_p16_kernel<gact::SplitLayoutAff<7, 13, true>, false>,
+                                                         gact::kBlockThreads, 0) != hipSuccess) {
+            delete e;
+            return fail(GACT_HIP_EDEVICE, "hipOccupancyMaxActiveBlocksPerMultiprocessor failed");
+        }
+        e->aff_grid_blocks = std::max(1, ab) * e->prop.multiProcessorCount;
+    }
     if (p->max_blocks > 0) {                // a small engine (gact_hip_params.max_blocks): every persistent grid capped, the workspace with them
-        for (int *g : {&e->grid_blocks, &e->seed_grid_blocks, &e->seed_lin_grid_blocks, &e->lin_grid_blocks, &e->wide_lin_grid_blocks})
+        for (int *g : {&e->grid_blocks, &e->seed_grid_blocks, &e->seed_lin_grid_blocks, &e->lin_grid_blocks, &e->wide_lin_grid_blocks, &e->aff_grid_blocks})
             *g = std::max(1, std::min(*g, (int)p->max_blocks));
     }
-    e->ws_words_total = ws_words_for(std::max(e->grid_blocks, std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
+    e->ws_words_total = ws_words_for(std::max(std::max(e->grid_blocks, e->aff_grid_blocks), std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
     if (big) {
         // one pointer matrix per wave (1 MB at 16 columns per lane, 4 MB at 32): at most 2 GiB per slot, two blocks per CU
         const size_t per_block = (gact::kBlockThreads / 64) * (e->big_cb == 16 ? gact::BigGeom<16>::kWsBytes : gact::BigGeom<32>::kWsBytes);
@@ -1557,7 +1578,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     st->packed16 = sl.two_phase ? (sl.wide ? 3 : e->split ? 2 : 1) : 0;
     st->seed_packed16 = (sl.two_phase && e->seed16) ? 1 : 0;
     st->tagged_pointers = (sl.two_phase && e->tagged) ? 1 : 0;
-    st->linear_gap = (sl.two_phase && sl.lin) ? 1 : 0;
+    st->linear_gap = (sl.two_phase && sl.lin) ? 1 : (sl.two_phase && sl.aff) ? 2 : 0;
     st->raw_candidates = sl.routed_raw;
     if (sl.two_phase) {
         HIP_TRY(hipEventElapsedTime(&st->seed_ms, sl.ev0, sl.ev_mid));

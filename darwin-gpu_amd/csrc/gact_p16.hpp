@@ -80,6 +80,7 @@ struct P16Consts {
     uint32_t next;      // -gap_extend
     uint32_t next4;     // -4 * gap_extend
     uint32_t ext4;      // 4 * gap_extend
+    int32_t s_mismatch, s_open, s_ext;    // the scores themselves (the drifted affine pass derives its constants, gact_aff.hpp)
 };
 
 __host__ __device__ inline uint32_t pk2(int v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
@@ -961,7 +962,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         __builtin_amdgcn_s_setprio(3);
         // FMT 3 walkers start from H[R][Q]: held by the lane of column Q when the pass ends
         int v0_h[kSlots] = {0, 0};
-        if (L::kWalkFmt == 3) {
+        if (L::kWalkFmt == 3 || L::kWalkFmt == 4) {
             v0_h[0] = (int)(int16_t)(__shfl(fin, L::fin_lane(pt.Q[0]), LANES) & 0xffffu);
             v0_h[1] = (int)(int16_t)(__shfl(fin, L::fin_lane(pt.Q[1]), LANES) >> 16);
         }
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
             int l0, c0, k0;
             L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
             // how far from the diagonal through (R, Q) a walk of this tile may be when it refills; -1: every block is there
-            const int band_lim = (L::kWalkFmt == 3 && (kp.band & 0xffff) > 0 && !(h ? pt.full[1] : pt.full[0]))
+            const int band_lim = ((L::kWalkFmt == 3 || L::kWalkFmt == 4) && (kp.band & 0xffff) > 0 && !(h ? pt.full[1] : pt.full[0]))
                                      ? (kp.band & 0xffff) - (kTeamWalk ? kLaBandMargin : kWalkBandMargin) : -1;
             if constexpr (kTeamWalk && GACT_EXP_FAKE_WALK) {
                 // timing experiment only (results are wrong): no walk, every tile taken as a diagonal of `early` steps

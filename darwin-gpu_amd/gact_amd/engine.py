@@ -372,7 +372,7 @@ class Engine:
         return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
                 "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split", "packed16-wide")[st.packed16],
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
-                "tagged_pointers": bool(st.tagged_pointers), "linear_gap": bool(st.linear_gap),
+                "tagged_pointers": bool(st.tagged_pointers), "linear_gap": st.linear_gap == 1, "affine_drift": st.linear_gap == 2,
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells, "raw_candidates": st.raw_candidates,
                 "band_redos": st.band_redos, "merged_callers": st.merged_callers, "overlapped_seeding": bool(st.overlapped_seeding)}
 

@@ -269,7 +269,8 @@ typedef struct {
     int32_t handed_off;                 /* candidates the main launch continued */
     int32_t seed_packed16;              /* 1: the seed launch ran the packed-int16 arg-max kernel, 0: the int32 one */
     int32_t tagged_pointers;            /* 1: the split layout ran its pointer phase on tagged scores */
-    int32_t linear_gap;                 /* 1: the main launch ran the linear-gap pass (open == extend == mismatch) */
+    int32_t linear_gap;                 /* which drifted pass the main launch ran: 1 the linear-gap pass (open == extend ==
+                                           mismatch, gact_lin.hpp), 2 the drifted affine pass (gact_aff.hpp), 0 neither */
     int64_t seed_cells;                 /* DP cells executed by the seed launch */
     int32_t raw_candidates;             /* candidates the run aligned from raw bytes because one of their two reads holds a byte
                                            other than A/C/G/T (align.cpp:134), while the rest ran on the 2-bit image; 0 when no

@@ -157,27 +157,34 @@ def test_overlapped_seeding_equals_the_plain_sequence():
     eng.close()
 
 
+@pytest.mark.parametrize("scoring", [(1, -1, -1, -1), (2, -3, -5, -2), (3, -2, -4, -2)], ids=["linear", "affine", "affine-mismatch-is-extend"])
 @pytest.mark.parametrize("band", [24, 0])
-def test_a_narrow_band_runs_tiles_again_and_changes_nothing(monkeypatch, oracle, band):
+def test_a_narrow_band_runs_tiles_again_and_changes_nothing(monkeypatch, oracle, band, scoring):
     """GACT_HIP_BAND=24: walks leave the stored band in a per cent or two of the tiles, which are run again with their whole
-    window stored; 0: no band at all.  Records against the oracle, both layouts of the linear-gap main launch."""
+    window stored; 0: no band at all.  Records against the oracle: both layouts of the linear-gap main launch, and the
+    drifted affine pass (split layout; both forms of its diagonal constant)."""
     from gact_amd import engine, synth
     monkeypatch.setenv("GACT_HIP_BAND", str(band))
     rs = synth.simulate_reads(150000, n_reads=110, seed=51, mean_len=8000, sd_len=2500, min_len=1500, max_len=15000)
     cf, cr = synth.synth_candidates(rs, seed=52, min_overlap=400, false_frac=0.1)
-    want = _oracle_records(oracle, rs, cf, cr)
+    linear = scoring[1] == scoring[2] == scoring[3]
+    cat, offs = rs.concat(); rcat, roffs = rs.concat(rc=True)
+    wf, _ = oracle.gact_many(cat, offs, cat, offs, cf, complement=False, same_file=True, scoring=scoring, n_threads=8)
+    wr, _ = oracle.gact_many(cat, offs, rcat, roffs, cr, complement=True, same_file=True, scoring=scoring, n_threads=8)
+    want = np.concatenate([wf, wr])
     cands = np.concatenate([cf, cr])
-    for force in ("GACT_HIP_NO_WIDE", "GACT_HIP_FORCE_WIDE"):
+    for force in ("GACT_HIP_NO_WIDE", "GACT_HIP_FORCE_WIDE") if linear else ("GACT_HIP_NO_WIDE",):
         monkeypatch.delenv("GACT_HIP_NO_WIDE", raising=False)
         monkeypatch.delenv("GACT_HIP_FORCE_WIDE", raising=False)
         monkeypatch.setenv(force, "1")
-        eng = engine.Engine()
+        eng = engine.Engine(scoring=scoring)
         _load(eng, rs)
         eng.candidates_upload(cands)
         eng.candidates_run_mixed(len(cands), rc_from=len(cf))
         got = eng.candidates_fetch(len(cands)).copy()
         st = eng.last_run_stats()
-        assert st["linear_gap"] and st["layout"] == ("packed16-split" if force == "GACT_HIP_NO_WIDE" else "packed16-wide")
+        assert st["linear_gap"] == linear and st["affine_drift"] == (not linear)
+        assert st["layout"] == ("packed16-split" if force == "GACT_HIP_NO_WIDE" else "packed16-wide")
         assert (st["band_redos"] > 0) == (band == 24), st
         _same(got, want)
         eng.close()

@@ -23,7 +23,11 @@ FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitte
 MODES = [{}, {"GACT_HIP_FORCE_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_TAGGED": "1"},
          {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_FORCE_UNIFORM": "1"},
          {"GACT_HIP_FORCE_INT32_SEED": "1"}, {"GACT_HIP_FORCE_INT32": "1"},
-         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_LIN": "1"}, {"GACT_HIP_FORCE_WIDE": "1", "GACT_HIP_NO_LIN": "1"}]
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_LIN": "1"}, {"GACT_HIP_FORCE_WIDE": "1", "GACT_HIP_NO_LIN": "1"},
+         # round 4: the tagged affine pass of round 1 instead of the drifted one; a narrow band (second runs) and none
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_AFF": "1", "GACT_HIP_NO_LIN": "1"},
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_BAND": "24"}, {"GACT_HIP_BAND": "0"},
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_LIN": "1", "GACT_HIP_BAND": "24"}]
 ALL = sorted({k for m in MODES for k in m})
 t0 = time.time()
 total = 0
@@ -40,6 +44,9 @@ for it in range(n_cfg):
     thr = int(rng.integers(1, 70))
     match = int(rng.integers(1, 7))
     scoring = (match, -int(rng.integers(0, 8)), -int(rng.integers(0, 12)), -int(rng.integers(0, 6)))
+    if rng.random() < 0.6:                       # gap_open <= gap_extend, as scorings are in practice: the drifted affine pass
+        ext = -int(rng.integers(0, 5))
+        scoring = (match, -int(rng.integers(0, 8)), ext - int(rng.integers(0, 9)), ext)
     if rng.random() < 0.5:                       # linear gaps (open == extend == mismatch): the drifted pass
         g = -int(rng.choice([0, 1, 1, 1, 2, 3, 5, 9]))
         scoring = (match, g, g, g)
@@ -95,7 +102,7 @@ for it in range(n_cfg):
             else:
                 got = eng.extend(cands, complement=comp, same_file=True)
                 st = eng.last_run_stats()
-            key = ("big" if big else st["layout"] + ("-lin" if st["linear_gap"] else "") + "/" + st["seed_layout"]) + (
+            key = ("big" if big else st["layout"] + ("-lin" if st["linear_gap"] else "-aff" if st.get("affine_drift") else "") + "/" + st["seed_layout"]) + (
                 "+routed" if st["raw_candidates"] else "")
             layouts[key] = layouts.get(key, 0) + 1
             for f in FIELDS:

@@ -62,6 +62,7 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
             b = d["sq"]["_bench"]
             if b["kernel"] != kernel or b["kernel_cells"] != cells:
                 continue
+            # (per launch: tools/pmc_summary.py averages over the launches of a pass since round 4)
             sq = next(v for k, v in d["sq"].items() if k.startswith("extend"))
             wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if k.startswith("extend") and "WRITE_SIZE" in v)
             rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if k.startswith("extend") and "FETCH_SIZE" in v)
@@ -435,6 +436,9 @@ def main():
                        # slot of its own (stream, queues, workspace) -- what the reference's 8 feeder threads with a GPU_storage
                        # each do (darwin.cpp:619-629); every step is complete, records on the host, inside the timed region
                        "slots_in_flight": S,
+                       # every pass over the candidate list this process made (warm-up, timed region, the one-at-a-time leg, the
+                       # roofline leg and its warm-up): what a profile of this command has to be divided by
+                       "passes_in_this_process": args.warmup + args.steps + (n_single if S > 1 else 0) + 1 + n_roof,
                        "arch": info["arch"], "gen_seconds": round(t_gen, 1)},
             "roofline": roofline,
             # the same pass one step at a time (launch, wait, fetch, then the next): the figure of rounds 1 and 2

@@ -239,6 +239,7 @@ struct gact_hip_engine {
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
+    bool team_when_shared = false;      // GACT_HIP_TEAM_WHEN_SHARED=1: a split linear-gap launch that shares the machine walks by teams
     bool overlap_seed = true;   // GACT_HIP_NO_OVERLAP unset: a large run on an idle engine seeds in length order, most of it beside its main launch
     bool side_lane = true;      // GACT_HIP_NO_SIDE_LANE unset: few raw-byte candidates run beside the 2-bit launches (launch_extend)
     bool route_other = true;    // GACT_HIP_NO_ROUTING unset: raw-byte kernels only for candidates with a non-ACGT read
@@ -446,6 +447,18 @@ gact::ChainQueues queues(const Lane &ln, Slot &sl)
     return q;
 }
 
+// the second stream of overlapped seeding (run_pass)
+int ensure_aux_stream(Slot &sl)
+{
+    if (sl.aux_stream) return 0;
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(hipStreamCreateWithPriority(&sl.aux_stream, hipStreamNonBlocking, hi));
+    HIP_TRY(hipEventCreateWithFlags(&sl.aux_ev_a, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl.aux_ev_b, hipEventDisableTiming));
+    return 0;
+}
+
 // device arrays of a slot for a list of n candidates
 int reserve_candidates(Slot &sl, size_t n)
 {
@@ -604,13 +617,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                 count <= 4 * narrow_slots0 &&         // (a larger run: the seed phase is a few per cent of it, and two main launches
                                                       //  side by side cost about as much -- pacbio50mb, 334 k candidates: +1.4 %)
                 e->lin_grid_blocks >= 3) {
-                if (!sl.aux_stream) {
-                    int lo = 0, hi = 0;
-                    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-                    HIP_TRY(hipStreamCreateWithPriority(&sl.aux_stream, hipStreamNonBlocking, hi));
-                    HIP_TRY(hipEventCreateWithFlags(&sl.aux_ev_a, hipEventDisableTiming));
-                    HIP_TRY(hipEventCreateWithFlags(&sl.aux_ev_b, hipEventDisableTiming));
-                }
+                { int arc = ensure_aux_stream(sl); if (arc) return arc; }
                 const int ob = std::max(1, std::min((count + 255) / 256, 1024));
                 hipLaunchKernelGGL(gact::order_hist_kernel, dim3(ob), dim3(256), 0, ln.stream, sl.cands.p, first, count, rc_from, d_rs.offsets,
                                    d_qf.offsets, d_qr.offsets, kp.early, ln.d_counter + kOrderHist);
@@ -705,7 +712,9 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         const bool aff = e->aff && !raw && !wide && C == 20;
         if (first_pass) { sl.wide = wide; sl.lin = lin; sl.aff = aff; }
         auto km = lin ? (wide ? extend_p16_kernel<gact::WideLayoutLin, false>
-                              : extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>)
+                              : (shared_machine && ln.stream == sl.stream && e->team_when_shared)
+                                    ? extend_p16_kernel<gact::SplitLayoutLinTeam<7, 13>, false>
+                                    : extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>)
                 : aff ? (e->params.mismatch < e->params.gap_extend ? extend_p16_kernel<gact::SplitLayoutAff<7, 13, true>, false>
                                                                    : extend_p16_kernel<gact::SplitLayoutAff<7, 13, false>, false>)
                 : wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
@@ -814,7 +823,10 @@ int lin_occupancy_blocks(int *out)
     int a = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>,
                                                          gact::kBlockThreads, 0));
-    *out = std::max(1, a);
+    int b = a;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::extend_p16_kernel<gact::SplitLayoutLinTeam<7, 13>, false>,
+                                                         gact::kBlockThreads, 0));
+    *out = std::max(1, std::min(a, b));
     return 0;
 }
 
@@ -944,6 +956,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->side_lane = getenv("GACT_HIP_NO_SIDE_LANE") == nullptr;
     e->shared_hint = getenv("GACT_HIP_NO_SHARED_HINT") == nullptr;
     e->overlap_seed = getenv("GACT_HIP_NO_OVERLAP") == nullptr;
+    e->team_when_shared = getenv("GACT_HIP_TEAM_WHEN_SHARED") != nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
     if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
     if (const char *v = getenv("GACT_HIP_POISON_WS")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
@@ -1044,7 +1057,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     if (const char *v = getenv("GACT_HIP_COMBINE_US")) e->cb.window_us = std::max(0, atoi(v));
     e->cb.n_merge = (e->cb.enabled && p->n_slots > 1) ? 2 : 0;
     e->slots.resize(p->n_slots + e->cb.n_merge);            // (never resized again: references into it stay good)
-    for (int k = 0; k < p->n_slots; k++)
+    // (the first merge slot with the callers' slots: its 1.3 GB would otherwise be allocated inside the first merged launch)
+    for (int k = 0; k < p->n_slots + (e->cb.n_merge ? 1 : 0); k++)
         if ((rc = init_slot(e, e->slots[k]))) { gact_hip_destroy(e); return rc; }
     *out = e;
     return 0;
@@ -1272,7 +1286,14 @@ static int launch_run(gact_hip_engine *e, Slot &sl, int first, int n, int rc_fro
 static int launch_merged(gact_hip_engine *e, const std::vector<RunReq *> &batch)
 {
     Combiner &cb = e->cb;
-    const int m = e->n_user + (cb.next_merge++ % cb.n_merge);
+    // a merge slot whose last launch has ended (its arrays are the right size already, most of the time); all busy: take turns
+    int m = -1;
+    for (int k = 0; k < cb.n_merge && m < 0; k++) {
+        const Slot &c = e->slots[e->n_user + k];
+        if (!c.stream || !c.timed || hipEventQuery(c.ev_ready) == hipSuccess) m = e->n_user + k;
+    }
+    (void)hipGetLastError();
+    if (m < 0) m = e->n_user + (cb.next_merge++ % cb.n_merge);
     Slot &ms = e->slots[m];
     int rc = init_slot(e, ms);
     if (rc) return rc;
@@ -1334,13 +1355,14 @@ static int combined_submit(gact_hip_engine *e, int slot, int first, int n, int r
         cb.leader = true;
         // ---- collect: slots another thread called for within the last few milliseconds, with nothing in flight and
         //      nothing pending, are about to submit (feeder threads behind their barrier, darwin.cpp:408-422)
-        const auto deadline = clock::now() + std::chrono::microseconds(cb.window_us);
         const auto me = std::this_thread::get_id();
         // (a thread's first run on this engine: it may be one of a group that has just been started -- every idle slot
-        //  somebody else called for counts, however long ago)
+        //  counts, whoever called for it last and however long ago, also the ones nobody has called for yet, and the
+        //  window is three times as long: once per thread)
         thread_local const gact_hip_engine *submitted_to = nullptr;
         const bool first_run = submitted_to != e;
         submitted_to = e;
+        const auto deadline = clock::now() + std::chrono::microseconds(first_run ? 3 * cb.window_us : cb.window_us);
         for (;;) {
             const auto now = clock::now();
             int expected = 0;
@@ -1348,7 +1370,7 @@ static int combined_submit(gact_hip_engine *e, int slot, int first, int n, int r
                 const Slot &o = e->slots[k];
                 bool is_pending = false;
                 for (const RunReq *r : cb.pending) is_pending |= r->slot == k;
-                if (is_pending || o.last_thread == me || o.last_thread == std::thread::id()) continue;
+                if (is_pending || o.last_thread == me || (o.last_thread == std::thread::id() && !first_run)) continue;
                 if (o.in_flight) {
                     // a run in flight whose launch has ended: its thread is inside its fetch, or about to call it, and will
                     // be back in a moment (the other members of the launch this thread has just fetched from)
@@ -1595,6 +1617,56 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
             int64_t sc = 0;
             memcpy(&sc, &c[2], sizeof(int64_t));
             st->seed_cells += sc;
+        }
+    }
+    return 0;
+}
+
+int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates)
+{
+    if (!e) return fail(GACT_HIP_EINVAL, "prepare: engine is NULL");
+    if (expected_candidates < 0) return fail(GACT_HIP_EINVAL, "prepare: expected_candidates %d", expected_candidates);
+    int rc = set_device(e);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(e->cb.mu);
+    const int n_slots = e->n_user + (e->cb.n_merge ? 1 : 0);
+    for (int k = 0; k < n_slots; k++) {
+        Slot &sl = e->slots[k];
+        if ((rc = init_slot(e, sl))) return rc;
+        // a merge slot holds a whole job, a caller's slot its share of it (twice over: shares are uneven)
+        const size_t n = k >= e->n_user ? (size_t)expected_candidates
+                                        : std::min<size_t>((size_t)expected_candidates, 2 * (size_t)expected_candidates / (size_t)e->n_user + 1024);
+        if (n && reserve_candidates(sl, n)) return fail(GACT_HIP_ENOMEM, "prepare: device allocation failed (%zu candidates)", n);
+        if (e->p16 && e->lin && e->split && e->C == 20) {
+            // every stream this slot launches on sees the chain kernels once, with nothing to do: code and scratch are in place
+            if ((rc = ensure_aux_stream(sl))) return rc;
+            if (!n && reserve_candidates(sl, 1024)) return fail(GACT_HIP_ENOMEM, "prepare: device allocation failed");
+            const SeqSet &rs = e->sets[GACT_SET_REF];
+            if (!rs.d_raw) continue;                                   // (no read set yet: nothing valid to pass)
+            const gact::SeqSetDev d = rs.dev(false);
+            HIP_TRY(hipMemsetAsync(sl.d_counter, 0, kCounterInts * sizeof(int), sl.stream));
+            HIP_TRY(hipMemsetAsync(sl.d_counter + 7, 0xff, sizeof(int), sl.stream));       // "the second set is open" (and empty)
+            HIP_TRY(hipStreamSynchronize(sl.stream));
+            const Lane own = main_lane(e, sl);
+            gact::ChainQueues q = queues(own, sl);
+            q.list = sl.order.p; q.list_n = 0;
+            gact::ChainQueues q2 = q;                                  // the two-set variant: both sets empty, the flag set
+            {
+                const gact::ChainQueues s2 = second_queues(own, sl);
+                q2.more_flag = sl.d_counter + 7;
+                q2.more_count = s2.bucket_count; q2.more_pop = s2.bucket_pop; q2.more_live = s2.live;
+            }
+            for (hipStream_t st : {sl.stream, sl.aux_stream}) {
+                hipLaunchKernelGGL((gact::seed_p16_kernel<20, false, true>), dim3(1), dim3(gact::kBlockThreads), 0, st, e->kp, e->kc, d, d, d,
+                                   sl.cands.p, 0, 0, 0, 0, sl.overlaps.p, q, sl.d_ws);
+                hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(1), dim3(gact::kBlockThreads), 0, st, e->kp,
+                                   e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
+                hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>), dim3(1), dim3(gact::kBlockThreads), 0, st,
+                                   e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q2, sl.d_ws);
+                HIP_TRY(hipGetLastError());
+            }
+            HIP_TRY(hipStreamSynchronize(sl.stream));
+            HIP_TRY(hipStreamSynchronize(sl.aux_stream));
         }
     }
     return 0;

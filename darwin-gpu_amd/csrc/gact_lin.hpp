@@ -614,4 +614,13 @@ template <int C1, int C2> struct SplitLayoutLin : SplitLayout<C1, C2, true> {
     __device__ static int fin_lane(int Q) { (void)Q; return kGroup - 1; }
 };
 
+// The same launch with the look-ahead walker (teams of eight lanes, gact_chain.hpp).  Alone on the machine the team makes
+// the split launch slower (+5 % on ecoli10x: a wave iteration lasts longer, and that is what a run waits for); with several
+// runs in flight what counts is instructions and the team walks in a third of the loop trips: +1.6 % with the team in every
+// launch, +0.3 % (noise) when only the launches that share the machine take it (round 4, profiles/r04/ab_team_walker.txt).
+// Off by default; GACT_HIP_TEAM_WHEN_SHARED=1 makes the engine take this variant for a launch that shares the machine.
+template <int C1, int C2> struct SplitLayoutLinTeam : SplitLayoutLin<C1, C2> {
+    static constexpr bool kTeamWalk = true;
+};
+
 }  // namespace gact

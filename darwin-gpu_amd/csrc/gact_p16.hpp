@@ -770,11 +770,13 @@ template <class L> constexpr int walk_span()
 #ifndef GACT_WALK_TEAM
 #define GACT_WALK_TEAM -1
 #endif
+template <class L, class = void> struct layout_team_walk : std::false_type {};
+template <class L> struct layout_team_walk<L, std::enable_if_t<L::kTeamWalk>> : std::true_type {};
 template <class L> constexpr bool walk_by_team()
 {
     if constexpr (L::kWalkFmt != 3) return false;
     else if (GACT_WALK_TEAM >= 0) return GACT_WALK_TEAM != 0;
-    else return L::kLanes == 32;
+    else return L::kLanes == 32 || layout_team_walk<L>::value;       // (a layout may ask for the team: SplitLayoutLinTeam)
 }
 template <class L, bool TEAM> constexpr int walk_scratch_words()
 {

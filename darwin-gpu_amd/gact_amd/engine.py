@@ -200,7 +200,7 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_last_kernel_ms", "gact_hip_last_run_stats", "gact_hip_device_overlaps", "gact_hip_stream",
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
            "gact_hip_candidates_download", "gact_hip_derive_revcomp", "gact_hip_register_output",
-           "gact_hip_unregister_output", "gact_hip_set_option")
+           "gact_hip_unregister_output", "gact_hip_set_option", "gact_hip_prepare")
 
 
 class Engine:
@@ -334,6 +334,13 @@ class Engine:
 
     def sync(self, slot=0):
         self._check(self.L.gact_hip_sync(self.h, slot))
+
+    def prepare(self, expected_candidates=0):
+        """arrays, second streams and empty launches ahead of the first job (include/gact_hip.h gact_hip_prepare)"""
+        if hasattr(self.L, "gact_hip_prepare"):
+            self.L.gact_hip_prepare.argtypes = [C.c_void_p, C.c_int32]
+            self.L.gact_hip_prepare.restype = C.c_int
+            self._check(self.L.gact_hip_prepare(self.h, int(expected_candidates)))
 
     def set_option(self, name, value):
         """scheduling switches of a live engine: "overlap_seed", "combine", "combine_window_us" (include/gact_hip.h)"""

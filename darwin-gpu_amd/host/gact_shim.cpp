@@ -61,6 +61,30 @@ void ensure_reads_resident()
     });
 }
 
+// the bytes of gact.cpp:214-224 appended to `buf` (what gact_hip_format_overlap's snprintf makes, without the format
+// parsing: a feeder thread prints thousands of lines per batch, inside the time the reference reports as "Time GACT calling")
+void append_int(std::string &buf, int v)
+{
+    char tmp[12];
+    int n = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) tmp[n++] = '-';
+    while (n) buf.push_back(tmp[--n]);
+}
+void append_overlap(std::string &buf, const gact_overlap &o)
+{
+    buf += "ref_id: "; buf += reference_descrips[o.ref_id][0];
+    buf += ", query_id: "; buf += reads_descrips[o.query_id][0];
+    buf += ", ab: "; append_int(buf, o.ab);
+    buf += ", ae: "; append_int(buf, o.ae);
+    buf += ", bb: "; append_int(buf, o.bb);
+    buf += ", be: "; append_int(buf, o.be);
+    buf += ", score: "; append_int(buf, o.score);
+    buf += ", comp: "; append_int(buf, o.comp);
+    buf += '\n';
+}
+
 void print_overlap(std::ofstream &fout, const gact_overlap &o)
 {
     char line[1024];
@@ -68,7 +92,6 @@ void print_overlap(std::ofstream &fout, const gact_overlap &o)
                                     reads_descrips[o.query_id][0].c_str(), line, sizeof line);
     if (n < 0) die("gact_hip_format_overlap");
     fout.write(line, n);
-    fout.flush();
 }
 
 // The reference is single-device (cudaSetDevice(0), cuda_host.cu:195).  One process per GPU is how this engine
@@ -193,11 +216,30 @@ long run_and_print(gact_hip_engine *e, int slot, const std::vector<gact_candidat
     std::vector<gact_overlap> out((size_t)n);
     const auto t1 = std::chrono::high_resolution_clock::now();
     SAFE(gact_hip_candidates_upload(e, slot, n, cands.data()));
+    const auto tu = std::chrono::high_resolution_clock::now();
     SAFE(gact_hip_candidates_run_mixed(e, slot, 0, n, rc_from, same_file ? 1 : 0));
+    const auto tr = std::chrono::high_resolution_clock::now();
     SAFE(gact_hip_candidates_fetch(e, slot, n, out.data()));
     const auto t2 = std::chrono::high_resolution_clock::now();
-    for (int k = 0; k < n; k++)
-        if (out[k].emitted) print_overlap(k < rc_from ? fout_f : fout_r, out[k]);
+    if (time_prints()) {
+        auto us = [](std::chrono::high_resolution_clock::time_point a, std::chrono::high_resolution_clock::time_point b) {
+            return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        gact_hip_run_stats st;
+        memset(&st, 0, sizeof st);
+        (void)gact_hip_last_run_stats(e, slot, &st);
+        printf("time_gpu split, slot %d: upload %ld us, submit %ld us, wait + fetch %ld us (launch: %.2f ms on the device, %d callers merged)\n",
+               slot, us(t1, tu), us(tu, tr), us(tr, t2), st.total_ms, st.merged_callers);
+    }
+    // (gact.cpp:214-224 ends every line with std::endl; the lines of a batch are written and flushed together here)
+    std::string buf;
+    buf.reserve((size_t)n * 96);
+    for (int k = 0; k < rc_from && k < n; k++)
+        if (out[k].emitted) append_overlap(buf, out[k]);
+    if (&fout_r != &fout_f) { fout_f.write(buf.data(), (std::streamsize)buf.size()); fout_f.flush(); buf.clear(); }
+    for (int k = rc_from < n ? (rc_from < 0 ? 0 : rc_from) : n; k < n; k++)
+        if (out[k].emitted) append_overlap(buf, out[k]);
+    fout_r.write(buf.data(), (std::streamsize)buf.size());
+    fout_r.flush();
     return (long)std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
 }
 
@@ -231,6 +273,17 @@ void GPU_init(int tile_size_, int tile_overlap_, int gap_open, int gap_extend, i
         GPU_storage st;
         st.engine = g_main.engine; st.slot = i; st.reserved = 0;
         s->push_back(st);
+    }
+    // darwin.cpp has its three read sets in memory when it calls GPU_init (FASTA and reverse complements are read before
+    // :611): they become resident now, outside the feeder threads' "Time GACT calling".  (The -DGPU build recodes the
+    // strings to 0..3 afterwards, darwin.cpp:314-398; the engine takes either form and packs both to the same 2-bit image.)
+    // A caller whose reads come later gets them uploaded by its first batch, as before.
+    if (!reference_seqs.empty() && !reads_seqs.empty() && !rev_reads_seqs.empty()) {
+        ensure_reads_resident();
+        // (arrays for a job of ~16 candidates per read -- the filter's yield on 10x PacBio-shape reads is 14 --, streams, one
+        //  empty launch of the chain kernels: gact_hip.h gact_hip_prepare)
+        const size_t guess = std::min<size_t>(16 * reads_seqs.size(), (size_t)4 << 20);
+        SAFE(gact_hip_prepare(g_main.engine, (int32_t)guess));
     }
     gact_hip_device_info info;
     SAFE(gact_hip_get_device_info(g_main.engine, &info));
@@ -420,7 +473,7 @@ void GACT(char *ref_str, char *query_str, int ref_length, int query_length, int 
             c.ref_id = ref_id; c.query_id = query_id; c.ref_pos = ref_pos; c.query_pos = query_pos;
             gact_overlap o;
             SAFE(gact_hip_extend_candidates(g->e, it->second, 1, &c, complement ? 1 : 0, same_file ? 1 : 0, &o));
-            if (o.emitted) print_overlap(fout, o);                                       // gact.cpp:213
+            if (o.emitted) { print_overlap(fout, o); fout.flush(); }                      // gact.cpp:213
             return;
         }
     }
@@ -436,5 +489,5 @@ void GACT(char *ref_str, char *query_str, int ref_length, int query_length, int 
     gact_overlap o;
     SAFE(gact_hip_extend_candidates(e, 0, 1, &c, complement ? 1 : 0, 0, &o));
     o.ref_id = ref_id; o.query_id = query_id;
-    if (!(same_file && ref_id == query_id) && o.score > 0) print_overlap(fout, o);     // gact.cpp:213
+    if (!(same_file && ref_id == query_id) && o.score > 0) { print_overlap(fout, o); fout.flush(); }     // gact.cpp:213
 }

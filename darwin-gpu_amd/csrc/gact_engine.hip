@@ -236,6 +236,7 @@ struct gact_hip_engine {
     bool tagged = false;        // the packed main launch runs its pointer phase on tagged scores (any layout)
     bool lin = false;           // linear gaps (open == extend == mismatch): the drifted pass of gact_lin.hpp on 2-bit sets
     bool aff = false;           // any other scoring that fits: the drifted affine pass of gact_aff.hpp (split main launch, 2-bit sets)
+    bool aff_seed = true;       // ... and its first-tile form in the seed launch (GACT_HIP_NO_AFF_SEED: round 1's packed seed pass)
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
@@ -581,7 +582,9 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         fprintf(stderr, "done (popped %d)\n", dbg[0]);
         return 0;
     };
-    auto run_pass = [&](const Lane &ln, bool raw, const int *list, const int *list_count, int count, bool first_pass) -> int {
+    // second_set: the pass files and pops its chains in the lane's second set of queues (the raw-byte pass behind the 2-bit
+    // one on the same lane: the first set keeps its counts for the statistics, nothing is cleared between the passes)
+    auto run_pass = [&](const Lane &ln, bool raw, const int *list, const int *list_count, int count, bool first_pass, bool second_set = false) -> int {
         auto grid = [&](int needed, int occupancy_cap) { return std::max(1, std::min(needed, ln.max_blocks ? std::min(occupancy_cap, ln.max_blocks) : occupancy_cap)); };
         const int groups_needed = e->p16 ? (count + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave)
                                          : (count + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
@@ -589,7 +592,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         const int seed_blocks = grid((seed_waves + 3) / 4, e->grid_blocks);
         const int main_blocks = grid((groups_needed + 3) / 4, e->grid_blocks);
         const gact::SeqSetDev d_rs = rs.dev(raw), d_qf = qf.dev_or(raw, rs), d_qr = qr.dev_or(raw, rs);
-        gact::ChainQueues cq = queues(ln, sl);
+        gact::ChainQueues cq = second_set ? second_queues(ln, sl) : queues(ln, sl);
         cq.list = list; cq.list_count = list_count;
         if (trace) {
             fprintf(stderr, "[gact_hip] pass raw=%d listed=%d side=%d count=%d first=%d n=%d rc_from=%d\n", (int)raw, list != nullptr,
@@ -613,7 +616,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         if constexpr (C == 20) {
             const int narrow_slots0 = e->lin_grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
             if (e->overlap_seed && !raw && !list && !trace && !e->poison && e->seed16 && e->lin && e->split && e->wide <= 0 &&
-                !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 && count >= narrow_slots0 + narrow_slots0 / 2 &&
+                !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 && count >= narrow_slots0 + narrow_slots0 / 2 &&
                 count <= 4 * narrow_slots0 &&         // (a larger run: the seed phase is a few per cent of it, and two main launches
                                                       //  side by side cost about as much -- pacbio50mb, 334 k candidates: +1.4 %)
                 e->lin_grid_blocks >= 3) {
@@ -633,7 +636,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                                         count - 2 * narrow_slots0);
                 const size_t ws_split = ws_words_for(e, main1_blocks);
                 auto seed_blocks_for = [&](int cnt, int cap) { return std::max(1, std::min(((cnt + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave) + 3) / 4, cap)); };
-                auto kseed = gact::seed_p16_kernel<20, false, true>;
+                auto kseed = gact::seed_p16_kernel<20, false, 1>;
                 auto kmain = gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>;
                 // seed launch A
                 gact::ChainQueues qa = queues(ln, sl);
@@ -682,10 +685,12 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         if (e->seed16) {
             int blocks16 = grid((groups_needed + 3) / 4, e->seed_grid_blocks);
             auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
-            if constexpr (C == 20) {                     // the linear-gap seed pass exists for the 20-column geometry only
+            if constexpr (C == 20) {                     // the drifted seed passes exist for the 20-column geometry only
                 if (!raw && e->lin) {
-                    k16 = gact::seed_p16_kernel<C, false, true>;
+                    k16 = gact::seed_p16_kernel<C, false, 1>;
                     blocks16 = grid((groups_needed + 3) / 4, e->seed_lin_grid_blocks);
+                } else if (!raw && e->aff && e->aff_seed) {
+                    k16 = e->params.mismatch < e->params.gap_extend ? gact::seed_p16_kernel<C, false, 3> : gact::seed_p16_kernel<C, false, 2>;
                 }
             }
             hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, ln.stream,
@@ -774,19 +779,16 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         if ((rc = run_pass(side, true, sl.deferred.p + n, sl.d_counter + 5, routed[1], false))) return rc;
         HIP_TRY(hipEventRecord(sl.side_done, side.stream));
         sl.side_used = true;
-        if ((rc = run_pass(own, false, sl.deferred.p, sl.d_counter + 4, routed[0], true))) return rc;
-        HIP_TRY(hipStreamWaitEvent(sl.stream, sl.side_done, 0));
-        return 0;
+        rc = run_pass(own, false, sl.deferred.p, sl.d_counter + 4, routed[0], true);
+        // (also when the own lane's pass could not be launched: the side lane's launches are under way and write this run's records)
+        if (hipStreamWaitEvent(sl.stream, sl.side_done, 0) != hipSuccess && !rc) return fail(GACT_HIP_EDEVICE, "hipStreamWaitEvent failed");
+        return rc;
     }
     if (routed[0] > 0 && (rc = run_pass(own, false, sl.deferred.p, sl.d_counter + 4, routed[0], true))) return rc;
     if (routed[1] == 0) return 0;
-    if (routed[0] > 0) {
-        // the queues again from empty (the seed launches' cell counter and the two lists stay)
-        HIP_TRY(hipMemsetAsync(sl.d_counter, 0, sizeof(int), sl.stream));
-        HIP_TRY(hipMemsetAsync(sl.d_counter + 8, 0, (kCounterInts - 8) * sizeof(int), sl.stream));
-        { int prc = poison_ws(e, sl, 0x1b873593u); if (prc) return prc; }
-    }
-    return run_pass(own, true, sl.deferred.p + n, sl.d_counter + 5, routed[1], routed[0] == 0);
+    if (routed[0] > 0) { int prc = poison_ws(e, sl, 0x1b873593u); if (prc) return prc; }
+    // (behind a 2-bit pass on the same lane: the second set of queues, still empty)
+    return run_pass(own, true, sl.deferred.p + n, sl.d_counter + 5, routed[1], routed[0] == 0, routed[0] > 0);
 }
 
 template <int C> int occupancy_blocks(int *out)
@@ -836,8 +838,12 @@ template <int C> int seed_occupancy_blocks(int *out, int *out_lin)
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, gact::seed_p16_kernel<C, true>, gact::kBlockThreads, 0));
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, gact::seed_p16_kernel<C, false>, gact::kBlockThreads, 0));
     int c = b;
-    if constexpr (C == 20)
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::seed_p16_kernel<C, false, true>, gact::kBlockThreads, 0));
+    if constexpr (C == 20) {
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, gact::seed_p16_kernel<C, false, 1>, gact::kBlockThreads, 0));
+        int d = b;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, gact::seed_p16_kernel<C, false, 3>, gact::kBlockThreads, 0));
+        b = std::min(b, d);
+    }
     *out = std::max(1, std::min(a, b));
     *out_lin = std::max(1, c);          // the linear-gap seed kernel fits three waves per SIMD
     return 0;
@@ -950,6 +956,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
              getenv("GACT_HIP_NO_LIN") == nullptr;
     e->aff = e->tagged && e->split && !e->lin && gact::p16_aff_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
              getenv("GACT_HIP_NO_AFF") == nullptr;
+    e->aff_seed = getenv("GACT_HIP_NO_AFF_SEED") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
@@ -1657,7 +1664,7 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates)
                 q2.more_count = s2.bucket_count; q2.more_pop = s2.bucket_pop; q2.more_live = s2.live;
             }
             for (hipStream_t st : {sl.stream, sl.aux_stream}) {
-                hipLaunchKernelGGL((gact::seed_p16_kernel<20, false, true>), dim3(1), dim3(gact::kBlockThreads), 0, st, e->kp, e->kc, d, d, d,
+                hipLaunchKernelGGL((gact::seed_p16_kernel<20, false, 1>), dim3(1), dim3(gact::kBlockThreads), 0, st, e->kp, e->kc, d, d, d,
                                    sl.cands.p, 0, 0, 0, 0, sl.overlaps.p, q, sl.d_ws);
                 hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(1), dim3(gact::kBlockThreads), 0, st, e->kp,
                                    e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);

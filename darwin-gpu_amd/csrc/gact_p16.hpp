@@ -1063,13 +1063,22 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
                                                 const int col_from = 0, const int band = 0, const int QA = 0, const int QB = 0,
                                                 const bool fullA = true, const bool fullB = true);
 
+// the drifted affine pass for first tiles (gact_aff.hpp)
+template <int C, bool CBNEG>
+__device__ __forceinline__ void dp_pass_aff_seed(const P16Consts &kc, const int gl, const uint16_t *__restrict__ ref16,
+                                                 const uint32_t (&qb)[C], const int T_end,
+                                                 uint32_t *__restrict__ wsA, uint32_t *__restrict__ wsB,
+                                                 const int (*RQ)[2], P16Best *pb);
+
 // ---------------------------------------------------------------------------
 // Packed seed launch: the first tile(s) of every candidate (arg-max, pointers of the
 // whole tile), two candidates per group, then the chain is handed to the main launch
 // (ChainQueues) exactly as the int32 seed launch does (extend_kernel, seed_mode).
 // Needs p16_argmax_ok on top of p16_scoring_ok.  LIN: linear gap scoring on 2-bit sets (gact_lin.hpp).
-template <int C, bool RAW, bool LIN = false>
-__global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
+// MODE: 0 round 1's affine pass (any scoring that fits int16, raw bytes or 2-bit), 1 the linear-gap pass, 2 / 3 the drifted
+// affine pass (gact_aff.hpp; 3: mismatch < gap_extend) -- 1..3 on 2-bit sets only
+template <int C, bool RAW, int MODE = 0>
+__global__ __launch_bounds__(kBlockThreads, MODE == 1 ? 3 : 2) void seed_p16_kernel(
     KParams kp, P16Consts kc, SeqSetDev refs, SeqSetDev qfwd, SeqSetDev qrc,
     const gact_candidate *__restrict__ cands, int first_cand, int n, int rc_from,
     int same_file, gact_overlap *__restrict__ out, ChainQueues cq,
@@ -1085,6 +1094,8 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
     constexpr int kScratchWords = kTbScratchWords > kStageHalf ? kTbScratchWords : kStageHalf;
     __shared__ __attribute__((aligned(16))) uint32_t tb_lds[kGroupsPerBlock][kSlots][kScratchWords];
 
+    constexpr bool LIN = MODE == 1, AFF = MODE >= 2;
+    static_assert(!(RAW && MODE != 0), "the drifted passes read 2-bit sets");
     const WaveCtx w = wave_ctx();
     const int group_in_block = (threadIdx.x >> 6) * kGroupsPerWave + w.g;
     uint8_t *ref8 = lds + group_in_block * G::kGroupLds;
@@ -1141,7 +1152,8 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
 
         P16Best pb;
         __builtin_amdgcn_s_setprio(0);
-        if (LIN) dp_pass_lin<C, kGroup, true>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, 0, 0, RQ, &pb);
+        if constexpr (LIN) dp_pass_lin<C, kGroup, true>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, 0, 0, RQ, &pb);
+        else if constexpr (AFF) dp_pass_aff_seed<C, MODE == 3>(kc, w.gl, ref16_lane, qb, T_end, wsA, wsB, RQ, &pb);
         else dp_pass_p16<C, true, RAW>(kc, w.gl, ref16_lane, qb, T_end, 1, wsA, wsB, RQ, &pb);
         __builtin_amdgcn_s_setprio(3);
 
@@ -1183,7 +1195,8 @@ __global__ __launch_bounds__(kBlockThreads, LIN ? 3 : 2) void seed_p16_kernel(
                                                                       kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0],
                                                                       h ? wsB : wsA, ws_all, -1, no_redo);
             } else if (mine) {
-                walk_chain<C, LIN ? 3 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4, kWsRow>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
+                // (FMT 4 carries the score of its cell like FMT 3: the arg-max)
+                walk_chain<C, LIN ? 3 : AFF ? 4 : 1, LIN ? ((C + 1) / 2 + 3) / 4 : C / 4, kWsRow>(h ? wsB : wsA, tb_lds[group_in_block][h], i0, j0, l0, (j0 - 1) - l0 * C,
                                                   i0 + l0 - 1, kp.early, ref8 + L::kRow0 * 2 + h, 2, q8 + h * G::kTileMax,
                                                   s.phase, kp, wk, ref_steps, query_steps, nst, h ? pb.best[1] : pb.best[0], ws_all);
             }

@@ -273,12 +273,16 @@ def main():
         last = gdist.run_pipelined(n_steps, in_flight, launch, lambda slot: complete(slot, record_ms))
         return last if last is not None else (None, None)
 
+    # (the caller says it keeps S runs in flight: every launch of the timed region takes the throughput layout, also the
+    #  first ones, which find the machine idle -- gact_hip_set_option "runs_in_flight")
+    eng.set_option("runs_in_flight", 1 if S > 1 else 0)
     run_steps(args.warmup, S)
     barrier()
     t0 = time.perf_counter()
     rec, gathered = run_steps(args.steps, S)
     barrier()
     dt = time.perf_counter() - t0
+    eng.set_option("runs_in_flight", 0)
     # the same steps one at a time (launched, waited for, fetched), as the figure of rounds 1-2: `single_slot`
     n_single, dt_single = args.steps, dt / max(args.steps, 1)
     if S > 1:
@@ -307,6 +311,9 @@ def main():
             rank_sums = gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
         except RuntimeError as err:
             raise SystemExit("bench.py: %s" % err)
+        # the same gather once more through the C-ABI's own RCCL path (gact_hip_comm_*, what host/darwin_hip --rccl-gather
+        # uses), outside the timed region, compared on rank 0 with what torch.distributed delivered
+        cpp_gather = cpp_gather_check(eng, dist, rank, world, nf + nr, gathered)
     for k in sorted(ran - {0}):    # every slot that took a step holds the same records
         if eng.candidates_fetch(nf + nr, slot=k).tobytes() != eng.candidates_fetch(nf + nr, slot=0).tobytes():
             raise SystemExit("bench.py: slot %d's records differ from slot 0's" % k)
@@ -454,7 +461,7 @@ def main():
             out["config"]["gathered_records"] = int(sum(len(g) for g in gathered))
             out["config"]["gather"] = {"ranks": world, "records_per_rank": [int(len(g)) for g in gathered],
                                        "crc32_per_rank": rank_sums if isinstance(rank_sums, list) else None,
-                                       "gen_seconds_per_rank": gen_all}
+                                       "gen_seconds_per_rank": gen_all, "c_abi_rccl_gather": cpp_gather}
 
         if not args.no_cpu:
             out["cpu_baseline"], out["parity"] = cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr)
@@ -470,11 +477,62 @@ def main():
             out["variants"] = [variant_config(v, args.workload, reads, my_cf, my_cr) for v in VARIANTS]
         print(json.dumps(out))
         sys.stdout.flush()
+    if use_dist and _CPP_GATHER_STUCK:
+        os._exit(0)            # a collective of the C-ABI check never came back on this rank: its thread cannot be joined
     if eng is not None:
         eng.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+_CPP_GATHER_STUCK = False
+
+
+def cpp_gather_check(eng, dist, rank, world, n, gathered):
+    """One gather of slot 0's records over the C-ABI's RCCL path (include/gact_hip.h gact_hip_comm_create / _gather_lines),
+    every rank; rank 0 compares the lines with what the torch.distributed gather of the step delivered.  Run on a thread
+    with a time limit: the check must never keep the bench line from being printed."""
+    global _CPP_GATHER_STUCK
+    import tempfile
+    import threading
+    import uuid
+    import numpy as np
+    from gact_amd import engine
+    tok = [uuid.uuid4().hex if rank == 0 else None]
+    dist.broadcast_object_list(tok, src=0)
+    path = os.path.join(tempfile.gettempdir(), "gact_rccl_%s.id" % tok[0])
+    res = {}
+
+    def work():
+        try:
+            t0 = time.perf_counter()
+            comm = engine.Comm(eng, rank, world, path, timeout_s=30)
+            t1 = time.perf_counter()
+            counts, lines = comm.gather_lines(n, slot=0)
+            t2 = time.perf_counter()
+            counts, lines = comm.gather_lines(n, slot=0)              # (the second one: buffers are in place)
+            res.update({"create_ms": round((t1 - t0) * 1e3, 1), "first_gather_ms": round((t2 - t1) * 1e3, 2),
+                        "gather_ms": round((time.perf_counter() - t2) * 1e3, 2), "counts": [int(c) for c in counts], "lines": lines})
+            comm.close()
+        except Exception as err:                                       # (reported in the line, not fatal)
+            res["error"] = str(err)[:300]
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(120)
+    if th.is_alive():
+        _CPP_GATHER_STUCK = True
+        return {"ok": False, "error": "no answer within 120 s"}
+    if "error" in res:
+        return {"ok": False, "error": res["error"]}
+    out = {"ok": True, "records_per_rank": res["counts"], "create_ms": res["create_ms"], "first_gather_ms": res["first_gather_ms"],
+           "gather_ms": res["gather_ms"]}
+    if rank == 0 and gathered is not None:
+        want = np.concatenate([np.ascontiguousarray(g) for g in gathered]) if len(gathered) else np.zeros(0, dtype=engine.Comm.LINE_DTYPE)
+        out["equals_torch_distributed_gather"] = bool(want.tobytes() == res["lines"].tobytes())
+        out["ok"] = out["equals_torch_distributed_gather"]
+    return out
 
 
 def cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr):
@@ -695,10 +753,12 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
                     eng.candidates_fetch(nf + nr, slot=(k - (S - 1)) % S, out=recs[(k - (S - 1)) % S])
             for k in range(max(n - (S - 1), 0), n):
                 eng.candidates_fetch(nf + nr, slot=k % S, out=recs[k % S])
+        eng.set_option("runs_in_flight", 1)          # (every launch the throughput layout, the first ones too: see main())
         run_steps(S)
         t0 = time.perf_counter()
         run_steps(2 * S)
         dt = (time.perf_counter() - t0) / (2 * S)
+        eng.set_option("runs_in_flight", 0)
         for k in range(1, S):
             if recs[k].tobytes() != rec.tobytes():
                 raise SystemExit("bench.py: slot %d's records differ from slot 0's on %s" % (k, head))

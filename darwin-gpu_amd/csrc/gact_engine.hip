@@ -8,6 +8,11 @@
 //
 // There is deliberately no CPU path in this file.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>           // types of the RCCL entry points gact_gather.hpp looks up at run time (nothing is linked)
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -147,6 +152,9 @@ struct Slot {
     uint32_t *side_ws = nullptr;
     int side_blocks = 0;                 // grid the side workspace is sized for
     bool side_used = false;              // the last run had launches on it
+    gact_candidate *h_stage = nullptr;  // pinned staging for candidates_upload: hipMemcpyAsync from the caller's pageable array
+    size_t h_stage_cap = 0;             // has the runtime pin those pages first, and with eight feeder threads at it at once
+                                        // that call took 8 ms for some of them (profiles/r04/upload_trace_*.txt)
     gact_overlap *h_records = nullptr;  // pinned staging for candidates_fetch (pageable D2H is staged by the runtime
     size_t h_records_cap = 0;           // in small chunks: 0.2-0.9 ms for 3.7 MB; pinned + memcpy: 0.25 ms)
     // a caller-owned output buffer page-locked on request (gact_hip_register_output): fetches whose destination lies
@@ -240,6 +248,7 @@ struct gact_hip_engine {
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
+    std::atomic<bool> caller_keeps_runs_in_flight{false};      // set_option("runs_in_flight", 1): the caller says so itself -- every launch takes the throughput layout
     bool team_when_shared = false;      // GACT_HIP_TEAM_WHEN_SHARED=1: a split linear-gap launch that shares the machine walks by teams
     bool overlap_seed = true;   // GACT_HIP_NO_OVERLAP unset: a large run on an idle engine seeds in length order, most of it beside its main launch
     bool side_lane = true;      // GACT_HIP_NO_SIDE_LANE unset: few raw-byte candidates run beside the 2-bit launches (launch_extend)
@@ -563,8 +572,8 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     // Is another slot of this engine still running?  Then this launch shares the machine (feeder threads, steps in
     // flight) and what counts is throughput: the wide layout -- faster per chain, slower per cell, made for a launch
     // that has the CUs to itself and lasts as long as its longest chain -- is not taken on its own account.
-    bool shared_machine = false;
-    if (e->shared_hint)
+    bool shared_machine = e->caller_keeps_runs_in_flight.load(std::memory_order_relaxed);
+    if (e->shared_hint && !shared_machine)
         for (const Slot &other : e->slots)
             if (&other != &sl && other.timed && other.ev1 && hipEventQuery(other.ev1) == hipErrorNotReady) { shared_machine = true; break; }
     (void)hipGetLastError();                 // (hipErrorNotReady is an answer, not a failure)
@@ -1097,6 +1106,7 @@ void gact_hip_destroy(gact_hip_engine *e)
         if (sl.side_ws) (void)hipFree(sl.side_ws);
         if (sl.side_done) (void)hipEventDestroy(sl.side_done);
         if (sl.side_stream) (void)hipStreamDestroy(sl.side_stream);
+        if (sl.h_stage) (void)hipHostFree(sl.h_stage);
         if (sl.h_records) (void)hipHostFree(sl.h_records);
         if (sl.reg_out) { (void)hipHostUnregister(sl.reg_out); (void)hipGetLastError(); }
         if (sl.ev_ready) (void)hipEventDestroy(sl.ev_ready);
@@ -1234,13 +1244,40 @@ int gact_hip_align_tiles_inline(gact_hip_engine *e, int slot, int32_t n, const u
                      states_stride);
 }
 
+// pinned host staging of a slot for jobs of n candidates: the upload's source, the fetch's destination (no pinned memory
+// to be had: the copies go through the caller's own arrays, as before)
+static void reserve_host_staging(Slot &sl, size_t n)
+{
+    if (n > sl.h_stage_cap) {
+        if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+        sl.h_stage = nullptr; sl.h_stage_cap = 0;
+        const size_t want = std::max<size_t>(n + n / 4, 4096);
+        if (hipHostMalloc((void **)&sl.h_stage, want * sizeof(gact_candidate), hipHostMallocDefault) == hipSuccess) sl.h_stage_cap = want;
+        else (void)hipGetLastError();
+    }
+    if (n > sl.h_records_cap) {
+        if (sl.h_records) (void)hipHostFree(sl.h_records);
+        sl.h_records = nullptr; sl.h_records_cap = 0;
+        const size_t want = std::max<size_t>(n + n / 4, 4096);
+        if (hipHostMalloc((void **)&sl.h_records, want * sizeof(gact_overlap), hipHostMallocDefault) == hipSuccess) sl.h_records_cap = want;
+        else (void)hipGetLastError();
+    }
+}
+
 int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const gact_candidate *cands)
 {
     int rc = check_slot(e, slot);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !cands)) return fail(GACT_HIP_EINVAL, "candidates_upload: bad arguments");
+    // GACT_HIP_TRACE_UPLOAD: where an upload's time goes, per call, on stderr (microseconds since the call began)
+    static const bool trace_up = getenv("GACT_HIP_TRACE_UPLOAD") != nullptr;
+    const auto tu0 = std::chrono::steady_clock::now();
+    long tu[6] = {0, 0, 0, 0, 0, 0};
+    auto mark = [&](int k) { if (trace_up) tu[k] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tu0).count(); };
     if ((rc = set_device(e))) return rc;
+    mark(0);
     note_call(e, slot);
+    mark(1);
     Slot &sl = e->slots[slot];
     const SeqSet &rs = e->sets[GACT_SET_REF];
     const SeqSet &qf = e->sets[GACT_SET_QUERY], &qr = e->sets[GACT_SET_QUERY_RC];
@@ -1256,15 +1293,29 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
         if (c.ref_pos < 0 || c.ref_pos > rl || c.query_pos < 0)
             return fail(GACT_HIP_ERANGE, "candidate %d: position outside its read", k);
     }
+    mark(2);
     if (reserve_candidates(sl, (size_t)n))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");
     sl.n_cands = 0;
     sl.h_cands.assign(cands, cands + n);
     sl.checked_key[0] = -1;
     sl.cands_epoch = -1;
-    if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, cands, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
+    reserve_host_staging(sl, (size_t)n);
+    const gact_candidate *src = cands;
+    if (n && sl.h_stage_cap >= (size_t)n) {
+        // (nothing reads the staging array now: the one copy that does is waited for before its upload returns)
+        memcpy(sl.h_stage, cands, (size_t)n * sizeof(gact_candidate));
+        src = sl.h_stage;
+    }
+    mark(3);
+    if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, src, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
                                   sl.stream));
+    mark(4);
     HIP_TRY(hipStreamSynchronize(sl.stream));
+    mark(5);
+    if (trace_up)
+        fprintf(stderr, "[gact_hip] upload slot %d, %d candidates: set_device %ld, note_call %ld, checks %ld, reserve + host copy %ld, memcpyAsync %ld, sync %ld us\n",
+                slot, n, tu[0], tu[1], tu[2], tu[3], tu[4], tu[5]);
     sl.n_cands = (size_t)n;
     return 0;
 }
@@ -1508,15 +1559,7 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
         HIP_TRY(hipStreamSynchronize(sl.stream));
         return 0;
     }
-    if ((size_t)n > sl.h_records_cap) {
-        if (sl.h_records) (void)hipHostFree(sl.h_records);
-        sl.h_records = nullptr; sl.h_records_cap = 0;
-        const size_t want = std::max<size_t>((size_t)n, 4096);
-        if (hipHostMalloc((void **)&sl.h_records, want * sizeof(gact_overlap), hipHostMallocDefault) == hipSuccess)
-            sl.h_records_cap = want;
-        else
-            (void)hipGetLastError();        // no pinned memory: copy straight into the caller's buffer
-    }
+    if ((size_t)n > sl.h_records_cap) reserve_host_staging(sl, (size_t)n);     // (none to be had: straight into the caller's buffer)
     gact_overlap *dst = sl.h_records_cap >= (size_t)n ? sl.h_records : out;
     if (n) HIP_TRY(hipMemcpyAsync(dst, sl.overlaps.p, (size_t)n * sizeof(gact_overlap), hipMemcpyDeviceToHost,
                                   sl.stream));
@@ -1644,6 +1687,7 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates)
         const size_t n = k >= e->n_user ? (size_t)expected_candidates
                                         : std::min<size_t>((size_t)expected_candidates, 2 * (size_t)expected_candidates / (size_t)e->n_user + 1024);
         if (n && reserve_candidates(sl, n)) return fail(GACT_HIP_ENOMEM, "prepare: device allocation failed (%zu candidates)", n);
+        if (n && k < e->n_user) reserve_host_staging(sl, n);
         if (e->p16 && e->lin && e->split && e->C == 20) {
             // every stream this slot launches on sees the chain kernels once, with nothing to do: code and scratch are in place
             if ((rc = ensure_aux_stream(sl))) return rc;
@@ -1684,6 +1728,9 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
     if (!e || !name) return fail(GACT_HIP_EINVAL, "set_option: NULL argument");
     const std::string n(name);
     if (n == "overlap_seed") e->overlap_seed = value != 0;
+    // the caller keeps several runs in flight on this engine (steps of a pipeline, one slot each): what the engine otherwise
+    // guesses from the other slots' events at launch time -- and guesses differently from run to run for the first launches
+    else if (n == "runs_in_flight") e->caller_keeps_runs_in_flight.store(value != 0);
     else if (n == "combine") {
         std::lock_guard<std::mutex> lk(e->cb.mu);
         e->cb.enabled = value != 0 && e->cb.n_merge > 0;
@@ -1739,6 +1786,7 @@ int gact_hip_measure_valu_rate(gact_hip_engine *e, double *lane_ops_per_s)
 }
 
 #include "dsoft_engine.hpp"      // gact_hip_dsoft_build / _query / candidates_download
+#include "gact_gather.hpp"       // gact_hip_comm_*: the RCCL gather of a sharded job
 
 #ifdef GACT_STAMPS
 // diagnostic build: per-wave (start, queues empty, end, iterations) of the last main launch

@@ -14,7 +14,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
            ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp", "gact_lin.hpp",
-            "dsoft_device.hpp", "dsoft_engine.hpp")] + \
+            "gact_aff.hpp", "gact_big.hpp", "gact_gather.hpp", "dsoft_device.hpp", "dsoft_engine.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
 SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2
@@ -181,6 +181,14 @@ def load():
     L.gact_hip_register_output.argtypes = [vp, C.c_int, vp, C.c_int64]
     L.gact_hip_unregister_output.argtypes = [vp, C.c_int]
     try:                                       # (an older build loaded through GACT_HIP_LIB_PATH for an A/B run has none)
+        L.gact_hip_comm_create.argtypes = [vp, i32, i32, C.c_char_p, i32, C.POINTER(vp)]
+        L.gact_hip_comm_gather_lines.argtypes = [vp, C.c_int, i32, vp, vp, C.c_int64]
+        L.gact_hip_comm_destroy.argtypes = [vp]
+        for name in ("comm_create", "comm_gather_lines", "comm_destroy"):
+            getattr(L, "gact_hip_" + name).restype = C.c_int
+    except AttributeError:
+        pass
+    try:
         L.gact_hip_set_option.argtypes = [vp, C.c_char_p, i32]
         L.gact_hip_set_option.restype = C.c_int
     except AttributeError:
@@ -200,7 +208,8 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_last_kernel_ms", "gact_hip_last_run_stats", "gact_hip_device_overlaps", "gact_hip_stream",
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
            "gact_hip_candidates_download", "gact_hip_derive_revcomp", "gact_hip_register_output",
-           "gact_hip_unregister_output", "gact_hip_set_option", "gact_hip_prepare")
+           "gact_hip_unregister_output", "gact_hip_set_option", "gact_hip_prepare",
+           "gact_hip_comm_create", "gact_hip_comm_gather_lines", "gact_hip_comm_destroy")
 
 
 class Engine:
@@ -397,6 +406,32 @@ class Engine:
         n = self._check(self.L.gact_hip_format_overlap(rec.ctypes.data, ref_name.encode(), query_name.encode(),
                                                        buf, 512))
         return buf.raw[:n].decode()
+
+
+class Comm:
+    """The C-ABI's own RCCL gather (include/gact_hip.h gact_hip_comm_*; csrc/gact_gather.hpp): what host/darwin_hip
+    --rccl-gather and any C caller use where bench.py uses torch.distributed.  Collective calls: every rank makes them."""
+
+    LINE_DTYPE = np.dtype([(n, "<i4") for n in ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp_emitted")])
+
+    def __init__(self, eng, rank, world, id_path, timeout_s=120):
+        self.eng, self.rank, self.world = eng, rank, world
+        self.h = C.c_void_p()
+        eng._check(eng.L.gact_hip_comm_create(eng.h, rank, world, id_path.encode(), int(timeout_s), C.byref(self.h)))
+
+    def gather_lines(self, n, slot=0, room=None):
+        """the first n records of `slot`, as 32-byte lines, to rank 0: (counts per rank, lines on rank 0 / None elsewhere)"""
+        counts = np.zeros(self.world, dtype=np.int64)
+        cap = int(room if room is not None else (n + 1) * self.world) if self.rank == 0 else 0
+        lines = np.zeros(cap, dtype=self.LINE_DTYPE) if self.rank == 0 else None
+        self.eng._check(self.eng.L.gact_hip_comm_gather_lines(self.h, slot, int(n), counts.ctypes.data,
+                                                              lines.ctypes.data if lines is not None else None, cap))
+        return counts, (lines[:int(counts.sum())] if lines is not None else None)
+
+    def close(self):
+        if self.h:
+            self.eng.L.gact_hip_comm_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def queue_from_tile(result, states, first):

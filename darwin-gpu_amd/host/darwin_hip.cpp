@@ -213,6 +213,66 @@ static void device_feeder(int cpu_id, int lo, int hi, GPU_storage s, std::vector
     print_stage("Time GACT calling", t1, now());                 // darwin.cpp:441
 }
 
+// --rccl-gather IDFILE (with --shard R/W): this rank's share as ONE run on the engine (no feeder threads: a run is fastest
+// with all of its candidates in one launch), then the job's one collective -- every rank's records to rank 0 over RCCL,
+// out of the engines' device arrays (gact_hip_comm_gather_lines) -- and rank 0 writes darwin.gathered.out: the lines of
+// rank 0, then rank 1's, ..., each rank's forward-strand lines first.  `cat darwin.*.out | sort | uniq` of the file-based
+// form and `sort | uniq` of this file are the same lines.
+static int gathered_run(const std::vector<std::vector<Cand> > &per_thread, const std::string &id_path)
+{
+    auto check = [](int rc, const char *what) {
+        if (rc != 0) { printf("\n%s failed: %s\n\n", what, gact_hip_last_error()); exit(-1); }
+    };
+    std::vector<gact_candidate> cands;
+    for (int comp = 0; comp < 2; comp++)
+        for (const auto &v : per_thread)
+            for (const Cand &c : v)
+                if ((c.comp != 0) == (comp != 0)) cands.push_back(gact_candidate{c.ref_id, c.query_id, c.ref_pos, c.query_pos});
+    int32_t nf = 0;
+    for (const auto &v : per_thread)
+        for (const Cand &c : v) nf += c.comp ? 0 : 1;
+    const int32_t n = (int32_t)cands.size();
+    std::vector<GPU_storage> s;
+    GPU_init(tile_size, tile_overlap, gap_open, gap_extend, match_score, mismatch_score, tile_size - tile_overlap, &s, 1);
+    gact_hip_engine *e = (gact_hip_engine *)s[0].engine;
+    gact_hip_comm *comm = nullptr;
+    check(gact_hip_comm_create(e, shard_rank, shard_world, id_path.c_str(), 0, &comm), "gact_hip_comm_create");
+    const Tick t0 = now();
+    check(gact_hip_candidates_upload(e, 0, n, cands.data()), "gact_hip_candidates_upload");
+    check(gact_hip_candidates_run_mixed(e, 0, 0, n, nf, same_file), "gact_hip_candidates_run_mixed");
+    const Tick t1 = now();
+    std::vector<int64_t> counts((size_t)shard_world, 0);
+    // (rank 0 cannot know the total before the call: room for every rank's share at its largest -- the deal is round-robin)
+    std::vector<gact_line> lines(shard_rank == 0 ? ((size_t)n + 1) * (size_t)shard_world : 0);
+    check(gact_hip_comm_gather_lines(comm, 0, n, counts.data(), shard_rank == 0 ? lines.data() : nullptr, (int64_t)lines.size()),
+          "gact_hip_comm_gather_lines");
+    const Tick t2 = now();
+    print_stage("Time GACT calling", t0, t1);                                   // darwin.cpp:441 (launch; the wait is in the gather)
+    print_stage("Time gathering records (RCCL)", t1, t2);
+    if (shard_rank == 0) {
+        int64_t total = 0;
+        printf("gathered records per rank:");
+        for (int r = 0; r < shard_world; r++) { printf(" %lld", (long long)counts[(size_t)r]); total += counts[(size_t)r]; }
+        printf("\n");
+        std::ofstream fout("darwin.gathered.out");
+        char line[1024];
+        for (int64_t k = 0; k < total; k++) {
+            const gact_line &l = lines[(size_t)k];
+            if (!(l.comp_emitted & 2)) continue;
+            gact_overlap o;
+            memset(&o, 0, sizeof o);
+            o.ref_id = l.ref_id; o.query_id = l.query_id; o.ab = l.ab; o.ae = l.ae; o.bb = l.bb; o.be = l.be;
+            o.score = l.score; o.comp = l.comp_emitted & 1; o.emitted = 1;
+            const int len = gact_hip_format_overlap(&o, reference_descrips[o.ref_id][0].c_str(), reads_descrips[o.query_id][0].c_str(),
+                                                    line, sizeof line);
+            fout.write(line, len);
+        }
+    }
+    gact_hip_comm_destroy(comm);
+    GPU_close(&s, 1);
+    return 0;
+}
+
 static void upload_set(gact_hip_engine *e, int which, const std::vector<std::string> &seqs)
 {
     std::vector<int64_t> offs(seqs.size() + 1, 0);
@@ -321,7 +381,7 @@ int main(int argc, char *argv[])
                         "[--params params.cfg]\n");
         return 1;
     }
-    std::string cand_path, dump_path, cfg_path = "params.cfg";
+    std::string cand_path, dump_path, cfg_path = "params.cfg", gather_id;
     bool dsoft_only = false, device_dsoft = false, recode = false;
     for (int a = 4; a < argc; a++) {
         if (!strcmp(argv[a], "--candidates") && a + 1 < argc) cand_path = argv[++a];
@@ -330,6 +390,7 @@ int main(int argc, char *argv[])
         else if (!strcmp(argv[a], "--dsoft-only")) dsoft_only = true;
         else if (!strcmp(argv[a], "--device-dsoft")) device_dsoft = true;
         else if (!strcmp(argv[a], "--recode")) recode = true;
+        else if (!strcmp(argv[a], "--rccl-gather") && a + 1 < argc) gather_id = argv[++a];
         else if (!strcmp(argv[a], "--device") && a + 1 < argc) setenv("GACT_HIP_DEVICE", argv[++a], 1);   // read by GPU_init
         else if (!strcmp(argv[a], "--shard") && a + 1 < argc) {
             if (sscanf(argv[++a], "%d/%d", &shard_rank, &shard_world) != 2 || shard_world < 1 || shard_rank < 0 ||
@@ -478,6 +539,8 @@ int main(int argc, char *argv[])
         recode_in_place(reference_seqs); recode_in_place(reads_seqs); recode_in_place(rev_reads_seqs);
         print_stage("Time converting bases", t0, now());                          // darwin.cpp:405
     }
+
+    if (!gather_id.empty()) return gathered_run(per_thread, gather_id);
 
     std::vector<GPU_storage> s;
     GPU_init(tile_size, tile_overlap, gap_open, gap_extend, match_score, mismatch_score, tile_size - tile_overlap,

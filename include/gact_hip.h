@@ -299,13 +299,41 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *                        beside the main launch (gact_hip_run_stats.overlapped_seeding); 0: seed launch, then one main launch
  *   "combine"            1 (default when n_slots > 1): runs that different threads submit on different slots at about the same
  *                        time are merged into one launch (gact_hip_run_stats.merged_callers); 0: every run its own launches
- *   "combine_window_us"  how long the first of such runs waits for the others at most (default 1000) */
+ *   "combine_window_us"  how long the first of such runs waits for the others at most (default 1000)
+ *   "runs_in_flight"     1: the caller keeps several runs in flight on this engine (a pipeline of steps, one slot each): every
+ *                        launch takes the layout with the better throughput.  0 (default): the engine looks at the other slots'
+ *                        events when a run is launched, which the first launches of a pipeline answer differently from run to run */
 int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value);
 
 /* device address of the slot's gact_overlap array (for an RCCL gather) */
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);
 /* the slot's hipStream_t as an opaque pointer */
 void *gact_hip_stream(gact_hip_engine *e, int slot);
+
+/* ---- multi-GPU: the one collective of a sharded job, for C / C++ callers ----
+ * One process per GPU, every process with its own engine and its share of the candidates (they shard with no exchange on the
+ * data path); what is left to do is bring the records together.  The reference is single-device (cuda_host.cu:195) and joins
+ * the output files of separate processes with `cat darwin.*.out | sort | uniq` (README:25); here rank 0 receives every
+ * rank's records with RCCL, out of the engines' device-resident record arrays, narrowed on the device to the 32 bytes a
+ * line is printed from (gact.cpp:214-224).  bench.py makes the same gather through torch.distributed (gact_amd/dist.py).
+ * RCCL is looked up when the first communicator is made (librccl.so.1; GACT_HIP_RCCL_LIB names another file): a
+ * single-GPU caller needs none. */
+typedef struct {
+    int32_t ref_id, query_id;
+    int32_t ab, ae, bb, be, score;
+    int32_t comp_emitted;       /* bit 0: comp, bit 1: emitted (gact_overlap) */
+} gact_line;
+typedef struct gact_hip_comm gact_hip_comm;
+/* Rank `rank` of `world` (collective: returns when every rank has called it).  The ranks find each other through id_path, a
+ * file name all of them can reach and that does not exist yet: rank 0 puts RCCL's unique id there, the others wait for it
+ * (timeout_s seconds, 0: 120), rank 0 removes it again.  The communicator works on the engine's device. */
+int gact_hip_comm_create(gact_hip_engine *e, int32_t rank, int32_t world, const char *id_path, int32_t timeout_s,
+                         gact_hip_comm **out);
+/* Collective.  The first n records of `slot` (its last run's; the call waits for that run on the device) travel to rank 0.
+ * counts[world] (every rank, may be NULL): records per rank.  lines (rank 0): all of them, rank after rank, each rank's in
+ * candidate order; lines_cap = room in `lines`, in records.  Other ranks pass NULL, 0. */
+int gact_hip_comm_gather_lines(gact_hip_comm *c, int slot, int32_t n, int64_t *counts, gact_line *lines, int64_t lines_cap);
+int gact_hip_comm_destroy(gact_hip_comm *c);
 
 /* measurement aid: sustained lane-ops/s of this device on the packed-int16 instructions the kernels are made of
  * (independent v_pk_add_i16 / v_pk_max_i16 streams, eight waves per SIMD, no memory) */

@@ -85,3 +85,24 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".c")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "gact_oracle" not in txt and "liboracle" not in txt, f
+
+
+def test_gather_entry_points_refuse_bad_arguments_and_the_line_record_is_the_python_sides(hip_lib_path, tmp_path):
+    """gact_hip_comm_* (the C++ side's RCCL gather): argument checks come before anything touches a device or RCCL; the
+    32-byte gact_line of the header is gact_amd/dist.py's LINE_DTYPE field for field"""
+    import subprocess
+    from gact_amd import dist
+    lib = ctypes.CDLL(hip_lib_path)
+    lib.gact_hip_last_error.restype = ctypes.c_char_p
+    out = ctypes.c_void_p()
+    assert lib.gact_hip_comm_create(None, 0, 1, b"id", 0, ctypes.byref(out)) != 0
+    assert b"NULL" in lib.gact_hip_last_error()
+    assert lib.gact_hip_comm_gather_lines(None, 0, 0, None, None, 0) != 0
+    assert lib.gact_hip_comm_destroy(None) == 0
+    names = [n for n in dist.LINE_DTYPE.names]
+    (tmp_path / "line.c").write_text(
+        "#include <stdio.h>\n#include <stddef.h>\n#include \"gact_hip.h\"\nint main(void) { printf(\"%zu\", sizeof(gact_line)); "
+        + " ".join('printf(" %%zu", offsetof(gact_line, %s));' % n for n in names) + " return 0; }\n")
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), "-o", str(tmp_path / "line"), str(tmp_path / "line.c")])
+    got = [int(v) for v in subprocess.check_output([str(tmp_path / "line")]).split()]
+    assert got == [dist.LINE_BYTES] + [dist.LINE_DTYPE.fields[n][1] for n in names]

@@ -39,6 +39,10 @@ def test_bench_force_dist_as_a_child_process(slots, steps):
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["steps"] == steps and res["config"]["slots_in_flight"] == slots
     assert res["config"]["gathered_records"] == res["config"]["candidates"] > 2000
     assert res["parity"]["bit_exact"] is True and res["parity"]["checked_candidates"] > 100
+    # the C-ABI's own RCCL gather (gact_hip_comm_*), made once more behind the timed region: the same lines
+    cg = res["config"]["gather"]["c_abi_rccl_gather"]
+    assert cg["ok"] is True and cg["equals_torch_distributed_gather"] is True, cg
+    assert cg["records_per_rank"] == [res["config"]["candidates"]]
 
 
 SCRIPT = r"""

@@ -243,3 +243,31 @@ def test_sharded_driver_union_equals_single_run(tmp_path):
         assert out.returncode == 0, out.stdout + out.stderr
     sharded = sorted(_lines(tmp_path, "darwin.[01].[0-9].out"))
     assert sharded == single and len(single) > 40
+
+
+def test_rccl_gather_of_the_cpp_driver_prints_the_single_run_lines(tmp_path):
+    """darwin_hip --shard 0/1 --rccl-gather ID: the rank's share as one run on the engine, then the C++ side's RCCL gather
+    (gact_hip_comm_create / _gather_lines: unique id through a file, counts once around, the lines out of the engine's device
+    array) and rank 0's darwin.gathered.out.  One GPU: a communicator of one rank (RCCL refuses two ranks on one device), so
+    what runs here is RCCL's loading, the communicator, the all-gather of the counts, the device-side narrowing to 32-byte
+    lines and the formatting; the send / receive pairs of ranks 1.. run on the driver's 8-GPU node only."""
+    from gact_amd import synth
+    rs = synth.simulate_reads(30000, n_reads=20, seed=271, mean_len=5000, sd_len=1200, min_len=800, max_len=9000)
+    cf, cr = synth.synth_candidates(rs, seed=272, min_overlap=300)
+    rs.write_fasta(str(tmp_path / "reads.fasta"))
+    (tmp_path / "params.cfg").write_text(CFG_GACT)
+    _write_cands(tmp_path / "cands.bin", cf, cr)
+    base = [_driver(), "reads.fasta", "reads.fasta", "2", "--candidates", "cands.bin", "--device", "0"]
+    out = subprocess.run(base, capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    single = sorted(_lines(tmp_path, "darwin.[0-9].out"))
+    out = subprocess.run(base + ["--shard", "0/1", "--rccl-gather", "rccl.id"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "gathered records per rank: %d" % (len(cf) + len(cr)) in out.stdout, out.stdout
+    gathered = sorted(_lines(tmp_path, "darwin.gathered.out"))
+    assert gathered == single and len(single) > 40
+    assert not (tmp_path / "rccl.id").exists()                      # rank 0 takes the id file away again
+    # a stale id file is somebody else's job: refused, loudly
+    (tmp_path / "rccl.id").write_bytes(b"x" * 128)
+    out = subprocess.run(base + ["--shard", "0/1", "--rccl-gather", "rccl.id"], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert out.returncode != 0 and "exists already" in out.stdout + out.stderr

@@ -36,6 +36,15 @@ def test_a_launch_beside_a_running_slot_takes_the_split_layout(monkeypatch):
     assert layouts[0] == "packed16-wide" and layouts[1] == layouts[2] == "packed16-split", layouts
     for r in recs:
         assert r.tobytes() == alone.tobytes()
+    # a caller that says it keeps runs in flight gets the throughput layout from the first launch on (on an idle machine too)
+    eng.set_option("runs_in_flight", 1)
+    eng.candidates_run_mixed(len(cands), rc_from=len(cf), slot=1)
+    assert eng.candidates_fetch(len(cands), slot=1).tobytes() == alone.tobytes()
+    assert eng.last_run_stats(1)["layout"] == "packed16-split"
+    eng.set_option("runs_in_flight", 0)
+    eng.candidates_run_mixed(len(cands), rc_from=len(cf), slot=1)
+    assert eng.candidates_fetch(len(cands), slot=1).tobytes() == alone.tobytes()
+    assert eng.last_run_stats(1)["layout"] == "packed16-wide"
     # ... and with the hint switched off every one of them is wide
     eng.close()
     monkeypatch.setenv("GACT_HIP_NO_SHARED_HINT", "1")

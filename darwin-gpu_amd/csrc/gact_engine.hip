@@ -152,6 +152,7 @@ struct Slot {
     uint32_t *side_ws = nullptr;
     int side_blocks = 0;                 // grid the side workspace is sized for
     bool side_used = false;              // the last run had launches on it
+    int stream_index = -1;              // of `stream` in the process's pool (StreamPool)
     gact_candidate *h_stage = nullptr;  // pinned staging for candidates_upload: hipMemcpyAsync from the caller's pageable array
     size_t h_stage_cap = 0;             // has the runtime pin those pages first, and with eight feeder threads at it at once
                                         // that call took 8 ms for some of them (profiles/r04/upload_trace_*.txt)
@@ -247,6 +248,7 @@ struct gact_hip_engine {
     bool aff_seed = true;       // ... and its first-tile form in the seed launch (GACT_HIP_NO_AFF_SEED: round 1's packed seed pass)
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
+    bool kernel_copies = true;  // GACT_HIP_SDMA_COPIES unset: candidate lists and records cross the bus in a kernel (bus_copy_kernel)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
     std::atomic<bool> caller_keeps_runs_in_flight{false};      // set_option("runs_in_flight", 1): the caller says so itself -- every launch takes the throughput layout
     bool team_when_shared = false;      // GACT_HIP_TEAM_WHEN_SHARED=1: a split linear-gap launch that shares the machine walks by teams
@@ -317,11 +319,46 @@ constexpr int kCounterInts = kOrderCursor + gact::kBuckets;
 // GACT_HIP_POISON_WS: seeded garbage over the slot's whole traceback workspace (poison_kernel)
 int poison_ws(gact_hip_engine *e, Slot &sl, uint32_t salt);
 
+// The slots' streams belong to the process, not to an engine: slot k of every engine on a device runs on the k-th stream the
+// process made there.  The runtime deals a process's streams onto few hardware queues (four unless GPU_MAX_HW_QUEUES says
+// otherwise) when they are first used, and launches of two streams that share a queue run one after the other.  The slots of
+// a process's FIRST engine get a queue each; the streams a later engine created did not -- the same four steps in flight took
+// 52-54 ms per step on an engine made after another one had been closed, 41-42 in a fresh process or with eight queues
+// (ONT shape, profiles/r04/hw_queue_sharing_side_configs.txt).  Streams are never destroyed; an engine hands them back idle.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::vector<std::pair<int, hipStream_t>>> idle;      // [device]: (index, stream)
+    std::vector<int> made;                                            // [device]: streams made so far
+    int take(int dev, hipStream_t *out)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if ((int)idle.size() <= dev) { idle.resize((size_t)dev + 1); made.resize((size_t)dev + 1, 0); }
+        auto &v = idle[(size_t)dev];
+        if (!v.empty()) {
+            size_t best = 0;
+            for (size_t k = 1; k < v.size(); k++) if (v[k].first < v[best].first) best = k;
+            *out = v[best].second;
+            const int idx = v[best].first;
+            v.erase(v.begin() + (long)best);
+            return idx;
+        }
+        if (hipStreamCreateWithFlags(out, hipStreamNonBlocking) != hipSuccess) return -1;
+        return made[(size_t)dev]++;
+    }
+    void give(int dev, int idx, hipStream_t s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if ((int)idle.size() <= dev) { idle.resize((size_t)dev + 1); made.resize((size_t)dev + 1, 0); }
+        idle[(size_t)dev].emplace_back(idx, s);
+    }
+};
+StreamPool g_streams;
+
 // stream, events, counters and traceback workspace of a slot (merge slots: on first use)
 int init_slot(gact_hip_engine *e, Slot &sl)
 {
     if (sl.stream) return 0;
-    if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess ||
+    if ((sl.stream_index = g_streams.take(e->params.device_id, &sl.stream)) < 0 ||
         hipEventCreate(&sl.ev0) != hipSuccess || hipEventCreate(&sl.ev1) != hipSuccess ||
         hipEventCreate(&sl.ev_mid) != hipSuccess ||
         hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming) != hipSuccess ||
@@ -966,6 +1003,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->aff = e->tagged && e->split && !e->lin && gact::p16_aff_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
              getenv("GACT_HIP_NO_AFF") == nullptr;
     e->aff_seed = getenv("GACT_HIP_NO_AFF_SEED") == nullptr;
+    e->kernel_copies = getenv("GACT_HIP_SDMA_COPIES") == nullptr;
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
@@ -1113,7 +1151,10 @@ void gact_hip_destroy(gact_hip_engine *e)
         if (sl.ev0) (void)hipEventDestroy(sl.ev0);
         if (sl.ev1) (void)hipEventDestroy(sl.ev1);
         if (sl.ev_mid) (void)hipEventDestroy(sl.ev_mid);
-        if (sl.stream) (void)hipStreamDestroy(sl.stream);
+        if (sl.stream) {
+            if (sl.stream_index >= 0) { (void)hipStreamSynchronize(sl.stream); g_streams.give(e->params.device_id, sl.stream_index, sl.stream); }
+            else (void)hipStreamDestroy(sl.stream);
+        }
     }
     for (auto &s : e->sets) s.release();
     e->dsoft.release_index();
@@ -1244,6 +1285,33 @@ int gact_hip_align_tiles_inline(gact_hip_engine *e, int slot, int32_t n, const u
                      states_stride);
 }
 
+// Small host <-> device transfers of a run -- the candidate list up, the records down -- made by a kernel that reads /
+// writes the pinned host array over the bus instead of hipMemcpyAsync.  The runtime hands such copies to the SDMA engines,
+// and an SDMA copy submitted while another stream's persistent launch is running came back only when a kernel of that
+// launch had ended: 8-14 ms inside hipMemcpyAsync for the feeder threads that met it (the reference's caller, 8 threads:
+// profiles/r04/upload_stall_runtime_settings.txt; HSA_ENABLE_SDMA=0 made them go away, and so does this).  Eight-byte
+// units: both record types are multiples of that.  GACT_HIP_SDMA_COPIES=1: hipMemcpyAsync as before.
+__global__ __launch_bounds__(256) void bus_copy_kernel(const uint2 *__restrict__ src, uint2 *__restrict__ dst, size_t n8)
+{
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n8; k += (size_t)gridDim.x * 256) dst[k] = src[k];
+}
+static int bus_copy(hipStream_t stream, const void *src, void *dst, size_t bytes)
+{
+    const size_t n8 = bytes / 8;
+    if (!n8) return 0;
+    hipLaunchKernelGGL(bus_copy_kernel, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n8 + 255) / 256, 512))), dim3(256), 0, stream,
+                       static_cast<const uint2 *>(src), static_cast<uint2 *>(dst), n8);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// the device's address of a pinned host array (hipHostMalloc / hipHostRegister); null: not mapped
+static void *device_view(void *host)
+{
+    void *d = nullptr;
+    if (!host || hipHostGetDevicePointer(&d, host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return d;
+}
+
 // pinned host staging of a slot for jobs of n candidates: the upload's source, the fetch's destination (no pinned memory
 // to be had: the copies go through the caller's own arrays, as before)
 static void reserve_host_staging(Slot &sl, size_t n)
@@ -1308,8 +1376,10 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
         src = sl.h_stage;
     }
     mark(3);
-    if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, src, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
-                                  sl.stream));
+    void *src_dev = (e->kernel_copies && src == sl.h_stage) ? device_view(sl.h_stage) : nullptr;
+    if (n && src_dev) { if ((rc = bus_copy(sl.stream, src_dev, sl.cands.p, (size_t)n * sizeof(gact_candidate)))) return rc; }
+    else if (n) HIP_TRY(hipMemcpyAsync(sl.cands.p, src, (size_t)n * sizeof(gact_candidate), hipMemcpyHostToDevice,
+                                       sl.stream));
     mark(4);
     HIP_TRY(hipStreamSynchronize(sl.stream));
     mark(5);
@@ -1555,16 +1625,29 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
     const size_t bytes = (size_t)n * sizeof(gact_overlap);
     if (n > 0 && sl.reg_out && (char *)out >= (char *)sl.reg_out &&
         (char *)out + bytes <= (char *)sl.reg_out + sl.reg_bytes) {
-        HIP_TRY(hipMemcpyAsync(out, sl.overlaps.p, bytes, hipMemcpyDeviceToHost, sl.stream));
+        void *out_dev = e->kernel_copies ? device_view(out) : nullptr;
+        if (out_dev) { if ((rc = bus_copy(sl.stream, sl.overlaps.p, out_dev, bytes))) return rc; }
+        else HIP_TRY(hipMemcpyAsync(out, sl.overlaps.p, bytes, hipMemcpyDeviceToHost, sl.stream));
         HIP_TRY(hipStreamSynchronize(sl.stream));
         return 0;
     }
+    static const bool trace_fetch = getenv("GACT_HIP_TRACE_UPLOAD") != nullptr;       // (the same switch as the upload's trace)
+    const auto tf0 = std::chrono::steady_clock::now();
+    long tf[3] = {0, 0, 0};
+    auto fmark = [&](int k) { if (trace_fetch) tf[k] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tf0).count(); };
     if ((size_t)n > sl.h_records_cap) reserve_host_staging(sl, (size_t)n);     // (none to be had: straight into the caller's buffer)
     gact_overlap *dst = sl.h_records_cap >= (size_t)n ? sl.h_records : out;
-    if (n) HIP_TRY(hipMemcpyAsync(dst, sl.overlaps.p, (size_t)n * sizeof(gact_overlap), hipMemcpyDeviceToHost,
-                                  sl.stream));
+    void *dst_dev = (e->kernel_copies && dst == sl.h_records) ? device_view(sl.h_records) : nullptr;
+    if (n && dst_dev) { if ((rc = bus_copy(sl.stream, sl.overlaps.p, dst_dev, (size_t)n * sizeof(gact_overlap)))) return rc; }
+    else if (n) HIP_TRY(hipMemcpyAsync(dst, sl.overlaps.p, (size_t)n * sizeof(gact_overlap), hipMemcpyDeviceToHost,
+                                       sl.stream));
+    fmark(0);
     HIP_TRY(hipStreamSynchronize(sl.stream));
+    fmark(1);
     if (n && dst != out) memcpy(out, dst, (size_t)n * sizeof(gact_overlap));
+    fmark(2);
+    if (trace_fetch)
+        fprintf(stderr, "[gact_hip] fetch slot %d, %d records: copy queued %ld, stream idle %ld, host copy %ld us (since the call began)\n", slot, n, tf[0], tf[1], tf[2]);
     return 0;
 }
 

@@ -76,7 +76,7 @@ for label, env in (("as it is (two calls per thread, one after the other)", {}),
                                                for a, b, c, d2, f, g in split],
                    "gact_calling_ms_max_over_threads": max(gact_ms), "gact_calling_ms_per_thread": gact_ms, "lines": len(lines),
                    "wall_s": round(wall, 1), "gcups_of_the_gact_stage": round(cells / (max(gact_ms) * 1e-3) / 1e9, 1)}
-            trace = [ln for ln in p.stderr.splitlines() if ln.startswith("[gact_hip] upload") or ln.startswith("[gact_hip] combiner")]
+            trace = [ln for ln in p.stderr.splitlines() if ln.startswith("[gact_hip] upload") or ln.startswith("[gact_hip] fetch") or ln.startswith("[gact_hip] combiner")]
             if trace:
                 row["engine_trace"] = trace
             if best is None or row["gact_calling_ms_max_over_threads"] < best["gact_calling_ms_max_over_threads"]:

@@ -292,6 +292,7 @@ def main():
         barrier()
         dt_single = (time.perf_counter() - t1) / n_single
     single_overlapped = bool(eng.last_run_stats(0)["overlapped_seeding"]) if nf + nr else False
+    single_lane = bool(eng.last_run_stats(0).get("critical_lane", False)) if nf + nr else False
     # ... and once more in the engine's plain sequence -- seed launch, then ONE main launch on the whole machine -- for the
     # per-kernel HIP-event times of `roofline`: a kernel's own duration is the time the chip spent on it only when it runs
     # alone (inside the timed region the kernels of S steps share the machine; and one at a time the engine seeds most of a
@@ -453,7 +454,9 @@ def main():
                             "ms_per_step": round(dt_single * 1e3, 3), "steps": n_single,
                             # (one at a time the engine seeds a run of this size in length order, most of it beside the main
                             #  launch: gact_hip_run_stats.overlapped_seeding)
-                            "overlapped_seeding": single_overlapped},
+                            "overlapped_seeding": single_overlapped,
+                            # (... and a wide launch beside the split one takes the longest chains: gact_hip_run_stats.critical_lane)
+                            "critical_lane": single_lane},
         }
         if gathered is not None:
             # what the one RCCL gather delivered: records per rank and each rank's own checksum of what it sent (compared on

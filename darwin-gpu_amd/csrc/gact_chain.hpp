@@ -693,6 +693,11 @@ struct ChainQueues {
     const int *more_flag;        // null: this launch has one set of queues
     int *more_count, *more_pop;  // [kBuckets] each
     int *more_live;
+    // The critical lane (gact_engine.hip run_pass): beside a split main launch a second, WIDE main launch on a third of the
+    // blocks pops the same queues -- a wave of it carries four tiles instead of eight and advances its chains about twice
+    // as fast.  Both pop longest-first; the split launch leaves the longest `leave_longest` chains of its (first) set to the
+    // lane -- it starts popping behind their length classes and comes back to them when it has nothing else.  0: no lane.
+    int leave_longest;
 };
 
 // next candidate of a seed launch into s (group-uniform; `leader` = the group's lane 0 does the atomic, bcast = a

@@ -64,6 +64,7 @@ struct SeqSet {
     int64_t *d_offsets = nullptr;
     int32_t *d_other = nullptr;   // per sequence: holds a byte other than A/C/G/T
     std::vector<int64_t> h_offsets;
+    std::vector<int32_t> h_other;     // host copy of d_other (empty: none of the set's sequences does)
     int32_t n = 0;
     int64_t total = 0;
     int64_t max_len = 0;      // longest sequence of the set
@@ -132,6 +133,7 @@ struct Slot {
     hipStream_t aux_stream = nullptr;    // overlapped seeding: the second seed launch and the main launch behind it
     hipEvent_t aux_ev_a = nullptr, aux_ev_b = nullptr;
     bool overlapped = false;             // the last run seeded while its main launch was running
+    bool lane = false;                   // ... had a critical lane (a wide main launch beside the split one)
     // call combiner (Combiner below; all under its mutex)
     std::thread::id last_thread;         // who called last for this slot, and when: is a run from it likely soon?
     std::chrono::steady_clock::time_point last_call{};
@@ -146,6 +148,7 @@ struct Slot {
     // side lane: queues, workspace and stream of the raw-byte launches that run BESIDE the 2-bit launches of a routed
     // run (launch_extend); made on first use
     hipStream_t side_stream = nullptr;
+    hipEvent_t side_go = nullptr;          // route_kernel has run: the side lane's launches may read its lists
     hipEvent_t side_done = nullptr;
     int *side_counter = nullptr;
     DevBuf<int> side_live;
@@ -153,6 +156,8 @@ struct Slot {
     int side_blocks = 0;                 // grid the side workspace is sized for
     bool side_used = false;              // the last run had launches on it
     int stream_index = -1;              // of `stream` in the process's pool (StreamPool)
+    int64_t routed_key[4] = {-1, -1, -1, -1};   // (first, n, rc_from, sets_epoch) routed_host was counted for
+    int routed_host[2] = {0, 0};        // candidates of that range whose reads are plain A/C/G/T / the rest (launch_extend)
     gact_candidate *h_stage = nullptr;  // pinned staging for candidates_upload: hipMemcpyAsync from the caller's pageable array
     size_t h_stage_cap = 0;             // has the runtime pin those pages first, and with eight feeder threads at it at once
                                         // that call took 8 ms for some of them (profiles/r04/upload_trace_*.txt)
@@ -248,6 +253,9 @@ struct gact_hip_engine {
     bool aff_seed = true;       // ... and its first-tile form in the seed launch (GACT_HIP_NO_AFF_SEED: round 1's packed seed pass)
     int wide = 0;               // wide (32 lanes per tile pair) main launch: 0 auto (few chains), 1 always, -1 never
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
+    bool crit_lane = true;      // GACT_HIP_NO_CRIT_LANE unset: a run of 1-1.5 chains per tile slot on an idle engine has a wide launch beside its split one
+    int lane_blocks = 0;                // GACT_HIP_LANE_BLOCKS=<n>: blocks of the lane (default: a third of the resident blocks)
+    bool crit_lane_always = false;      // GACT_HIP_CRIT_LANE_ALWAYS=1: ... and larger runs (up to 4 chains per slot) too
     bool kernel_copies = true;  // GACT_HIP_SDMA_COPIES unset: candidate lists and records cross the bus in a kernel (bus_copy_kernel)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
     std::atomic<bool> caller_keeps_runs_in_flight{false};      // set_option("runs_in_flight", 1): the caller says so itself -- every launch takes the throughput layout
@@ -430,6 +438,12 @@ int upload_set(gact_hip_engine *e, SeqSet &s, Slot &sl, const uint8_t *concat, c
     HIP_TRY(hipMemcpyAsync(&flags, sl.d_flags, sizeof(int), hipMemcpyDeviceToHost, sl.stream));
     HIP_TRY(hipStreamSynchronize(sl.stream));
     s.has_other = (flags & 1) != 0;
+    s.h_other.clear();
+    if (s.has_other) {
+        // which sequences: on the host too, so that a run over a list the host holds can count its two routes itself
+        s.h_other.resize((size_t)n_seqs);
+        HIP_TRY(hipMemcpy(s.h_other.data(), s.d_other, (size_t)n_seqs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     (void)e;
     return 0;
 }
@@ -491,6 +505,7 @@ gact::ChainQueues queues(const Lane &ln, Slot &sl)
     q.list_n = -1;
     q.more_flag = nullptr;
     q.more_count = q.more_pop = q.more_live = nullptr;
+    q.leave_longest = 0;
     return q;
 }
 
@@ -550,6 +565,7 @@ int side_lane(gact_hip_engine *e, Slot &sl, int count, int blocks, Lane *out)
         // ahead of the slot's own stream: its main launch must find room while the 2-bit seed launch drains
         HIP_TRY(hipStreamCreateWithPriority(&sl.side_stream, hipStreamNonBlocking, hi));
         HIP_TRY(hipEventCreateWithFlags(&sl.side_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sl.side_go, hipEventDisableTiming));
         HIP_TRY(hipMalloc((void **)&sl.side_counter, kCounterInts * sizeof(int)));
     }
     if (blocks > sl.side_blocks) {
@@ -606,6 +622,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     sl.two_phase = e->p16;
     sl.routed_raw = 0;
     sl.overlapped = false;
+    sl.lane = false;
     // Is another slot of this engine still running?  Then this launch shares the machine (feeder threads, steps in
     // flight) and what counts is throughput: the wide layout -- faster per chain, slower per cell, made for a launch
     // that has the CUs to itself and lasts as long as its longest chain -- is not taken on its own account.
@@ -684,6 +701,14 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                 auto seed_blocks_for = [&](int cnt, int cap) { return std::max(1, std::min(((cnt + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave) + 3) / 4, cap)); };
                 auto kseed = gact::seed_p16_kernel<20, false, 1>;
                 auto kmain = gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>;
+                // the critical lane (ChainQueues::leave_longest): main launch 2 in the wide layout -- its third of the blocks
+                // holds 16 tiles a block -- and main launch 1 leaves it that many of the longest chains
+                // (measured on ecoli10x, 2.7 chains per tile slot: a run that size is bound by throughput, and a third of the
+                //  waves in the wide layout cost 12 % of that -- main launches 34-35 ms instead of 29.5-30.3; the lane is for
+                //  runs of fewer chains, below.  GACT_HIP_CRIT_LANE_ALWAYS=1 takes it here too.)
+                const bool lane = e->crit_lane && e->crit_lane_always && main2_blocks <= e->wide_lin_grid_blocks;
+                auto kmain2 = lane ? gact::extend_p16_kernel<gact::WideLayoutLin, false, true> : kmain;
+                const int lane_tiles = main2_blocks * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
                 // seed launch A
                 gact::ChainQueues qa = queues(ln, sl);
                 qa.list = sl.order.p; qa.list_n = nA;
@@ -711,18 +736,19 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                     q2.more_count = s2.bucket_count; q2.more_pop = s2.bucket_pop; q2.more_live = s2.live;
                 }
                 if (count > nA) {
-                    hipLaunchKernelGGL(kmain, dim3(main2_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
+                    hipLaunchKernelGGL(kmain2, dim3(main2_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
                                        same_file, sl.overlaps.p, q2, ln.d_ws + ws_split);
                     HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
                 // main launch 1: set 1, then set 2
-                const gact::ChainQueues q1 = q2;
+                gact::ChainQueues q1 = q2;
+                if (lane && count > nA) q1.leave_longest = lane_tiles;
                 hipLaunchKernelGGL(kmain, dim3(main1_blocks), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr,
                                    same_file, sl.overlaps.p, q1, ln.d_ws);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
-                if (first_pass) { sl.wide = false; sl.lin = true; }
+                if (first_pass) { sl.wide = false; sl.lin = true; sl.lane = lane && count > nA; }
                 sl.overlapped = true;
                 return 0;
             }
@@ -790,6 +816,36 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         const int lin_blocks = grid((groups_needed + 3) / 4, lin_cap);
         const int aff_cap = e->aff_grid_blocks;
         const int main_blocks_now = aff ? grid((groups_needed + 3) / 4, aff_cap) : main_blocks;
+        if constexpr (C == 20) {
+            // The critical lane beside a run's ONE split main launch (a run too small for overlapped seeding, e.g. the merged
+            // forward-strand calls of eight feeder threads: 33 k chains on 24.6 k tile slots last as long as their longest
+            // chain): the wide launch on a third of the blocks, on the second stream, behind the seed launch like the split one
+            const int narrow_slots0 = e->lin_grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
+            // (GACT_HIP_LANE_BLOCKS=<n>: another size for the lane, the split launch takes the rest)
+            const int lane_blocks = e->lane_blocks > 0 ? std::min(e->lane_blocks, e->lin_grid_blocks / 2) : e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3;
+            if (e->crit_lane && lin && !wide && !raw && !trace && !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 &&
+                !e->team_when_shared && count > narrow_slots && (count < narrow_slots0 + narrow_slots0 / 2 || e->crit_lane_always) &&
+                count <= 4 * narrow_slots0 && e->lin_grid_blocks >= 3 &&
+                lane_blocks <= e->wide_lin_grid_blocks) {
+                { int arc = ensure_aux_stream(sl); if (arc) return arc; }
+                const int split_blocks = grid((groups_needed + 3) / 4, e->lin_grid_blocks - lane_blocks);
+                const size_t ws_split = ws_words_for(e, e->lin_grid_blocks - lane_blocks);
+                HIP_TRY(hipEventRecord(sl.aux_ev_a, ln.stream));
+                HIP_TRY(hipStreamWaitEvent(sl.aux_stream, sl.aux_ev_a, 0));
+                hipLaunchKernelGGL((extend_p16_kernel<gact::WideLayoutLin, false>), dim3(lane_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp,
+                                   e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws + ws_split);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
+                gact::ChainQueues cq1 = cq;
+                cq1.leave_longest = lane_blocks * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
+                hipLaunchKernelGGL(km, dim3(split_blocks), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr, same_file,
+                                   sl.overlaps.p, cq1, ln.d_ws);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
+                if (first_pass) sl.lane = true;
+                return 0;
+            }
+        }
         hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks_now)), dim3(gact::kBlockThreads), 0, ln.stream, kp,
                            e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws);
         HIP_TRY(hipGetLastError());
@@ -806,8 +862,30 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                        rc_from, o_rs.other, need_f ? o_qf.other : nullptr, need_r ? o_qr.other : nullptr, sl.deferred.p, sl.d_counter + 4);
     HIP_TRY(hipGetLastError());
     int routed[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(routed, sl.d_counter + 4, sizeof routed, hipMemcpyDeviceToHost, sl.stream));
-    HIP_TRY(hipStreamSynchronize(sl.stream));
+    // The two lists' lengths decide grids and layouts.  A list the host holds (uploaded, not merged, not made by the device
+    // filter) is counted on the host from the sets' per-sequence flags -- no wait: with other slots' persistent launches on
+    // the machine, route_kernel (14 registers: it does not fit beside three 168-register waves) starts only when a block of
+    // theirs has left, and the host sat in this wait for milliseconds (1 % dirty reads, four steps in flight: -10 %).
+    const bool host_counts = strands < 0 && !sl.h_cands.empty() && (size_t)first + (size_t)n <= sl.h_cands.size() &&
+                             (!rs.has_other || (int32_t)rs.h_other.size() == rs.n) && (!need_f || !qf.has_other || (int32_t)qf.h_other.size() == qf.n) &&
+                             (!need_r || !qr.has_other || (int32_t)qr.h_other.size() == qr.n);
+    if (host_counts) {
+        const int64_t key[4] = {first, n, rc_from, e->sets_epoch};
+        if (memcmp(key, sl.routed_key, sizeof key)) {
+            int dirty = 0;
+            for (int k = first; k < first + n; k++) {
+                const gact_candidate &c = sl.h_cands[(size_t)k];
+                const SeqSet &qs = k >= rc_from ? qr : qf;
+                dirty += ((rs.has_other && rs.h_other[(size_t)c.ref_id]) || (qs.has_other && qs.h_other[(size_t)c.query_id])) ? 1 : 0;
+            }
+            memcpy(sl.routed_key, key, sizeof key);
+            sl.routed_host[0] = n - dirty; sl.routed_host[1] = dirty;
+        }
+        routed[0] = sl.routed_host[0]; routed[1] = sl.routed_host[1];
+    } else {
+        HIP_TRY(hipMemcpyAsync(routed, sl.d_counter + 4, sizeof routed, hipMemcpyDeviceToHost, sl.stream));
+        HIP_TRY(hipStreamSynchronize(sl.stream));
+    }
     sl.routed_raw = routed[1];
     int rc = 0;
     // Few raw-byte candidates beside many others: their launches last as long as their longest chain (a wave alone on
@@ -820,6 +898,9 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     if (routed[0] > 0 && routed[1] > 0 && e->side_lane && raw_blocks <= side_cap) {
         Lane side;
         if ((rc = side_lane(e, sl, routed[1], std::max(raw_blocks, std::min(side_cap, 16)), &side))) return rc;
+        // (the side lane's launches read route_kernel's lists: behind it on the device, whether or not the host waited for it)
+        HIP_TRY(hipEventRecord(sl.side_go, sl.stream));
+        HIP_TRY(hipStreamWaitEvent(side.stream, sl.side_go, 0));
         HIP_TRY(hipMemsetAsync(side.d_counter, 0, kCounterInts * sizeof(int), side.stream));
         if ((rc = poison_lane(e, side, 0x1b873593u))) return rc;
         if ((rc = run_pass(side, true, sl.deferred.p + n, sl.d_counter + 5, routed[1], false))) return rc;
@@ -1004,6 +1085,9 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
              getenv("GACT_HIP_NO_AFF") == nullptr;
     e->aff_seed = getenv("GACT_HIP_NO_AFF_SEED") == nullptr;
     e->kernel_copies = getenv("GACT_HIP_SDMA_COPIES") == nullptr;
+    e->crit_lane = getenv("GACT_HIP_NO_CRIT_LANE") == nullptr;
+    e->crit_lane_always = getenv("GACT_HIP_CRIT_LANE_ALWAYS") != nullptr;
+    if (const char *v = getenv("GACT_HIP_LANE_BLOCKS")) e->lane_blocks = std::max(0, atoi(v));
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
@@ -1143,6 +1227,7 @@ void gact_hip_destroy(gact_hip_engine *e)
         if (sl.side_counter) (void)hipFree(sl.side_counter);
         if (sl.side_ws) (void)hipFree(sl.side_ws);
         if (sl.side_done) (void)hipEventDestroy(sl.side_done);
+        if (sl.side_go) (void)hipEventDestroy(sl.side_go);
         if (sl.side_stream) (void)hipStreamDestroy(sl.side_stream);
         if (sl.h_stage) (void)hipHostFree(sl.h_stage);
         if (sl.h_records) (void)hipHostFree(sl.h_records);
@@ -1226,6 +1311,11 @@ int gact_hip_derive_revcomp(gact_hip_engine *e)
         return fail(GACT_HIP_EINVAL, "derive_revcomp: Bad Nt char in GACT_SET_QUERY (darwin.cpp:139-141)");
     }
     qr.has_other = (flags & 1) != 0;
+    qr.h_other.clear();
+    if (qr.has_other) {
+        qr.h_other.resize((size_t)qf.n);
+        HIP_TRY(hipMemcpy(qr.h_other.data(), qr.d_other, (size_t)qf.n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
@@ -1367,6 +1457,7 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
     sl.n_cands = 0;
     sl.h_cands.assign(cands, cands + n);
     sl.checked_key[0] = -1;
+    sl.routed_key[0] = -1;
     sl.cands_epoch = -1;
     reserve_host_staging(sl, (size_t)n);
     const gact_candidate *src = cands;
@@ -1727,6 +1818,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     memset(st, 0, sizeof *st);
     st->merged_callers = merged_callers;
     st->overlapped_seeding = sl.overlapped ? 1 : 0;
+    st->critical_lane = sl.lane ? 1 : 0;
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
     st->main_ms = st->total_ms;

@@ -831,7 +831,16 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; }
     wave_sync();
     bool exhausted = false;
-    int my_bucket = 0;           // longest chains first (ChainQueues)
+    // longest chains first (ChainQueues) -- except that a launch with a critical lane beside it (cq.leave_longest, gact_chain.hpp)
+    // starts behind the classes that hold the longest `leave_longest` chains of its own set and comes back to them last:
+    // bucket = (bucket_first + my_bucket) mod kBuckets
+    int my_bucket = 0;
+    int bucket_first = 0;
+    if (cq.leave_longest > 0) {
+        int acc = 0;
+        while (bucket_first < kBuckets && (acc += cq.bucket_count[bucket_first]) <= cq.leave_longest) bucket_first++;
+        if (bucket_first >= kBuckets) bucket_first = 0;
+    }
     // the set of queues this group pops from: the launch's own, later (overlapped seeding) the second one.  (One flag per
     // lane, the pointers are picked where they are used: the DP loop owns the register file)
     bool second_set = false;
@@ -869,13 +878,14 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
                         while (my_bucket < kBuckets) {
                             // look before popping: an atomic on a class that is empty or drained is one of ~12,000
                             // (every group comes by) serialised on one address -- 4 ms of a 55 ms launch with 32 empty classes
-                            const int cnt = q_count[my_bucket];
+                            const int bkt = bucket_first + my_bucket - (bucket_first + my_bucket >= kBuckets ? kBuckets : 0);
+                            const int cnt = q_count[bkt];
                             int idx = cnt;
-                            if (w.gl == 0 && __hip_atomic_load(&q_pop[my_bucket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt)
-                                idx = atomicAdd(&q_pop[my_bucket], 1);
+                            if (w.gl == 0 && __hip_atomic_load(&q_pop[bkt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cnt)
+                                idx = atomicAdd(&q_pop[bkt], 1);
                             idx = __shfl(idx, 0, LANES);
                             if (idx < cnt) {
-                                cand = q_live[(size_t)my_bucket * cq.live_stride + idx];
+                                cand = q_live[(size_t)bkt * cq.live_stride + idx];
                                 break;
                             }
                             my_bucket++;

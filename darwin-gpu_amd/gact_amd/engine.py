@@ -48,7 +48,8 @@ class RunStats(C.Structure):
                 ("packed16", C.c_int32), ("handed_off", C.c_int32), ("seed_packed16", C.c_int32),
                 ("tagged_pointers", C.c_int32), ("linear_gap", C.c_int32), ("seed_cells", C.c_int64),
                 ("raw_candidates", C.c_int32), ("band_redos", C.c_int32),
-                ("merged_callers", C.c_int32), ("overlapped_seeding", C.c_int32)]
+                ("merged_callers", C.c_int32), ("overlapped_seeding", C.c_int32),
+                ("critical_lane", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class DsoftParams(C.Structure):
@@ -390,7 +391,8 @@ class Engine:
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
                 "tagged_pointers": bool(st.tagged_pointers), "linear_gap": st.linear_gap == 1, "affine_drift": st.linear_gap == 2,
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells, "raw_candidates": st.raw_candidates,
-                "band_redos": st.band_redos, "merged_callers": st.merged_callers, "overlapped_seeding": bool(st.overlapped_seeding)}
+                "band_redos": st.band_redos, "merged_callers": st.merged_callers, "overlapped_seeding": bool(st.overlapped_seeding),
+                "critical_lane": bool(st.critical_lane)}
 
     def measure_valu_rate(self):
         v = C.c_double()

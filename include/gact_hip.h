@@ -284,6 +284,9 @@ typedef struct {
     int32_t overlapped_seeding;         /* 1: the candidates were seeded in order of chain length, most of them beside the main
                                            launch (large runs on an otherwise idle engine); seed_ms is then the first seed launch
                                            alone and main_ms holds the rest */
+    int32_t critical_lane;              /* 1: beside the split main launch a wide one ran on a third of the blocks and took the
+                                           longest chains (runs of 1-4 chains per tile slot on an otherwise idle engine) */
+    int32_t reserved_;
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
 

@@ -157,6 +157,65 @@ def test_overlapped_seeding_equals_the_plain_sequence():
     eng.close()
 
 
+def test_the_critical_lane_changes_no_record(monkeypatch):
+    """A run of 1-1.5 chains per tile slot on an idle engine has a wide main launch beside its split one, on a third of the
+    blocks, and the split launch leaves it the longest chains (ChainQueues::leave_longest): a 30,000-candidate range of
+    ecoli10x (the lane beside the one main launch, as for the merged forward calls of the reference's feeder threads) and,
+    with GACT_HIP_CRIT_LANE_ALWAYS=1, ecoli10x whole (the overlapped sequence: main launch 2 is the lane).  Same records as
+    with GACT_HIP_NO_CRIT_LANE=1, run after run."""
+    from conftest import workload_block
+    from gact_amd import engine
+    blk = workload_block("ecoli10x")
+    cands = np.concatenate([blk.cf, blk.cr])
+    nf = len(blk.cf)
+    monkeypatch.setenv("GACT_HIP_NO_CRIT_LANE", "1")
+    eng = engine.Engine()
+    _load(eng, blk.rs)
+    eng.candidates_upload(cands)
+    eng.candidates_run_mixed(len(cands), rc_from=nf)
+    whole = eng.candidates_fetch(len(cands)).copy()
+    assert not eng.last_run_stats()["critical_lane"]
+    eng.candidates_run_mixed(30000, rc_from=nf, first=20000)
+    part = eng.candidates_fetch(len(cands))[20000:50000].copy()
+    assert not eng.last_run_stats()["critical_lane"]
+    eng.close()
+    monkeypatch.delenv("GACT_HIP_NO_CRIT_LANE")
+    eng = engine.Engine()
+    _load(eng, blk.rs)
+    eng.candidates_upload(cands)
+    eng.candidates_run_mixed(len(cands), rc_from=nf)
+    assert eng.candidates_fetch(len(cands)).tobytes() == whole.tobytes()
+    st = eng.last_run_stats()
+    assert st["overlapped_seeding"] and not st["critical_lane"], st          # (a run that size is bound by throughput)
+    eng.close()
+    monkeypatch.setenv("GACT_HIP_CRIT_LANE_ALWAYS", "1")
+    eng = engine.Engine()
+    _load(eng, blk.rs)
+    eng.candidates_upload(cands)
+    for rep in range(3):
+        eng.candidates_run_mixed(len(cands), rc_from=nf)
+        got = eng.candidates_fetch(len(cands))
+        st = eng.last_run_stats()
+        assert st["critical_lane"] and st["overlapped_seeding"], st
+        assert got.tobytes() == whole.tobytes()
+        eng.candidates_run_mixed(30000, rc_from=nf, first=20000)
+        got = eng.candidates_fetch(len(cands))[20000:50000]
+        st = eng.last_run_stats()
+        assert st["critical_lane"] and not st["overlapped_seeding"], st
+        assert got.tobytes() == part.tobytes()
+    # not for a run that shares the machine, nor for one small enough to be all wide
+    eng.set_option("runs_in_flight", 1)
+    eng.candidates_run_mixed(30000, rc_from=nf, first=20000)
+    assert eng.candidates_fetch(len(cands))[20000:50000].tobytes() == part.tobytes()
+    assert not eng.last_run_stats()["critical_lane"]
+    eng.set_option("runs_in_flight", 0)
+    eng.candidates_run_mixed(8000, rc_from=nf, first=20000)
+    assert eng.candidates_fetch(len(cands))[20000:28000].tobytes() == part[:8000].tobytes()
+    st = eng.last_run_stats()
+    assert not st["critical_lane"] and st["layout"] == "packed16-wide"
+    eng.close()
+
+
 @pytest.mark.parametrize("scoring", [(1, -1, -1, -1), (2, -3, -5, -2), (3, -2, -4, -2)], ids=["linear", "affine", "affine-mismatch-is-extend"])
 @pytest.mark.parametrize("band", [24, 0])
 def test_a_narrow_band_runs_tiles_again_and_changes_nothing(monkeypatch, oracle, band, scoring):

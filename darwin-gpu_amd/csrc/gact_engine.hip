@@ -902,6 +902,12 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         HIP_TRY(hipEventRecord(sl.side_go, sl.stream));
         HIP_TRY(hipStreamWaitEvent(side.stream, sl.side_go, 0));
         HIP_TRY(hipMemsetAsync(side.d_counter, 0, kCounterInts * sizeof(int), side.stream));
+        // ... and the slot's own launches behind the side lane's reset: "started first" has to hold on the DEVICE.  With the
+        // host no longer waiting for route_kernel the own lane's seed launch followed it at once, filled the machine, the own
+        // main launch after it, and the side lane's blocks found room when that had ended: 31 + 14 ms one after the other.
+        // Now both lanes' seed launches become eligible together and the side lane's stream has the higher priority.
+        HIP_TRY(hipEventRecord(sl.side_go, side.stream));
+        HIP_TRY(hipStreamWaitEvent(sl.stream, sl.side_go, 0));
         if ((rc = poison_lane(e, side, 0x1b873593u))) return rc;
         if ((rc = run_pass(side, true, sl.deferred.p + n, sl.d_counter + 5, routed[1], false))) return rc;
         HIP_TRY(hipEventRecord(sl.side_done, side.stream));

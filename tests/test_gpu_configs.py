@@ -333,4 +333,4 @@ def test_config2_eight_feeder_slots(capsys):
     # the engine merges the eight threads' runs into one launch (round 4): the threads together get what one caller with the
     # whole list gets, less the collect window and eight record copies (3,957 against 6,354 before, eight grids competing)
     assert all(m == 8 for m in rows[1]["callers_merged_in_last_launch"])
-    assert rows[1]["gcups"] > 0.8 * rows[0]["gcups"]
+    assert rows[1]["gcups"] > 0.85 * rows[0]["gcups"]

@@ -1587,7 +1587,13 @@ static int combined_submit(gact_hip_engine *e, int slot, int first, int n, int r
         thread_local const gact_hip_engine *submitted_to = nullptr;
         const bool first_run = submitted_to != e;
         submitted_to = e;
-        const auto deadline = clock::now() + std::chrono::microseconds(first_run ? 3 * cb.window_us : cb.window_us);
+        // (... and three times as long for a thread whose last run was merged with others': they are known to be there, between
+        //  their fetch and their next call -- line formatting and file writes in the reference's caller, 1-3 ms apart --, and a
+        //  run that misses the launch of its peers costs both launches far more than the wait: the reference's caller with a
+        //  group split 2 + 4 + 8 over its two calls printed 59 ms where 48 were due.  A peer that does not come back costs the
+        //  long wait once: the next launch's members are the ones that did.)
+        const bool had_peers = e->slots[slot].merged_into >= 0 && e->slots[slot].merged_callers > 1;
+        const auto deadline = clock::now() + std::chrono::microseconds((first_run || had_peers) ? 3 * cb.window_us : cb.window_us);
         for (;;) {
             const auto now = clock::now();
             int expected = 0;

@@ -54,8 +54,9 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
     here = os.path.dirname(os.path.abspath(__file__))
     if candidates != "dsoft":
         return None
+    # (newest round first, within a round the round-end pass before the earlier ones; a fresh clone has one mtime for all)
     paths = sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_*%s*.json" % workload_name)),
-                   key=lambda q: (os.path.basename(os.path.dirname(q)), os.path.getmtime(q)), reverse=True)
+                   key=lambda q: (os.path.basename(os.path.dirname(q)), "round_end" in os.path.basename(q), os.path.getmtime(q), q), reverse=True)
     for path in paths:
         try:
             d = json.load(open(path))
@@ -84,7 +85,7 @@ def pmc_default_lookup(workload_name, candidates, cells_per_step):
     if candidates != "dsoft":
         return None
     paths = sorted(glob.glob(os.path.join(here, "profiles", "r*", "pmc_default_*%s*.json" % workload_name)),
-                   key=lambda q: (os.path.basename(os.path.dirname(q)), os.path.getmtime(q)), reverse=True)
+                   key=lambda q: (os.path.basename(os.path.dirname(q)), "round_end" in os.path.basename(q), os.path.getmtime(q), q), reverse=True)
     for path in paths:
         try:
             d = json.load(open(path))

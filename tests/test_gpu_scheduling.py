@@ -203,6 +203,15 @@ def test_the_critical_lane_changes_no_record(monkeypatch):
         st = eng.last_run_stats()
         assert st["critical_lane"] and not st["overlapped_seeding"], st
         assert got.tobytes() == part.tobytes()
+    # random ranges of the size the lane is for (a candidate's record does not depend on what else is in the run)
+    rng = np.random.default_rng(404)
+    for _ in range(6):
+        n = int(rng.integers(25000, 36000))
+        first = int(rng.integers(0, len(cands) - n))
+        eng.candidates_run_mixed(n, rc_from=nf, first=first)
+        got = eng.candidates_fetch(len(cands))[first:first + n]
+        assert eng.last_run_stats()["critical_lane"]
+        assert got.tobytes() == whole[first:first + n].tobytes(), (first, n)
     # not for a run that shares the machine, nor for one small enough to be all wide
     eng.set_option("runs_in_flight", 1)
     eng.candidates_run_mixed(30000, rc_from=nf, first=20000)

@@ -87,3 +87,31 @@ def test_steps_in_flight_with_dirty_reads_keep_their_records(oracle):
     for f in ("ab", "ae", "bb", "be", "score", "emitted", "first_tile_score", "n_tiles", "cells"):
         assert np.array_equal(recs[0][f], want[f]), f
     eng.close()
+
+
+def test_bus_copies_and_sdma_copies_move_the_same_bytes(monkeypatch):
+    """candidate lists up and records down through the engine's bus_copy_kernel (default) or hipMemcpyAsync
+    (GACT_HIP_SDMA_COPIES=1), into the engine's own pinned array or a registered output: the same records"""
+    from gact_amd import engine, synth
+    rs = synth.simulate_reads(60000, n_reads=40, seed=31, mean_len=6000, sd_len=1500, min_len=1200, max_len=10000)
+    cf, cr = synth.synth_candidates(rs, seed=32, min_overlap=300, false_frac=0.1)
+    cands = np.concatenate([cf, cr])
+    got = {}
+    for mode in ("kernel", "sdma"):
+        if mode == "sdma":
+            monkeypatch.setenv("GACT_HIP_SDMA_COPIES", "1")
+        eng = engine.Engine(n_slots=2)
+        _load(eng, rs)
+        eng.candidates_upload(cands, slot=0)
+        eng.candidates_run_mixed(len(cands), rc_from=len(cf), slot=0)
+        plain = eng.candidates_fetch(len(cands), slot=0).copy()
+        out = np.zeros(len(cands) + 7, dtype=engine.OVERLAP_DTYPE)             # registered, fetched into at an offset
+        eng.register_output(out, slot=1)
+        eng.candidates_upload(cands[::-1].copy(), slot=1)
+        eng.candidates_upload(cands, slot=1)                                   # (a second upload reuses the staging array)
+        eng.candidates_run_mixed(len(cands), rc_from=len(cf), slot=1)
+        eng.candidates_fetch(len(cands), slot=1, out=out[7:])
+        assert out[7:].tobytes() == plain.tobytes() and not out[:7].tobytes().strip(b"\0")
+        got[mode] = plain
+        eng.close()
+    assert got["kernel"].tobytes() == got["sdma"].tobytes()

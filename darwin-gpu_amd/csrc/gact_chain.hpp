@@ -196,6 +196,14 @@ struct ScoreWalk {
 //     score off it -- a MATCH step the substitution score of its cell, an INSERT / DELETE step g; after a diagonal
 //     move v is H of the new cell, and ZERO means v == 0 (align.cpp:166-168: M <= 0, I <= 0, D <= 0, i.e. H == 0).
 // Position arithmetic, region cache and arguments as in walk_chain below.
+#ifndef GACT_LIN_WALK_SPAN
+#define GACT_LIN_WALK_SPAN 8
+#endif
+// moves between two refills of the one-lane linear-gap walker: 8, or 16 with tb_refill_oct16 (-DGACT_LIN_WALK_SPAN=16: measured
+// SLOWER, 7,218-7,321 GCUPS against 7,599-7,646 on ecoli10x with four steps in flight, main launch 31.7-32.4 ms against 30.2-30.9
+// -- eighteen 16-byte loads per walker and refill cost more than the round trips they save; profiles/r04/walk_span16_ab.txt)
+constexpr int kLinWalkSpan = GACT_LIN_WALK_SPAN;
+static_assert(kLinWalkSpan == 8 || kLinWalkSpan == 16, "GACT_LIN_WALK_SPAN");
 template <int CW, int QN, int ROW>
 __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scratch, int R, int Q, int l0, int c0, int k0,
                                                int early, const uint8_t *rrow, int rstride, const uint8_t *qrow,
@@ -219,17 +227,26 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
 #ifdef GACT_STAMPS_REFILL
     unsigned long long rf_clk = 0;
 #endif
-    // region cache: dword (c >> 1) + 8 * (k >> 3) of a lane's two cached blocks x two cached octets
+    // region cache: dword (c >> 1) + 8 * (k >> 3) of a lane's cached blocks x two cached octets
+    // (kLinWalkSpan 16: three lanes x three blocks x both octets, one refill per sixteen moves -- tb_refill_oct16;
+    //  8: round 2's two lanes x two blocks x two octets, one per eight)
+    int off2 = 0;
     auto refill = [&](int l, int c, int k) {
 #ifdef GACT_STAMPS_REFILL
         struct Acc { unsigned long long &sum, t0; __device__ ~Acc() { sum += __builtin_amdgcn_s_memtime() - t0; } } acc_{rf_clk, __builtin_amdgcn_s_memtime()};
 #endif
-        tb_refill_oct<CW, QN, ROW>(ws_all, ws_off, scratch, l, c, k, rg);
-        off0 = 4 * (-8 * rg.fbase[0] - 4 * rg.qbase0);
-        off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
+        if constexpr (kLinWalkSpan == 16) {
+            tb_refill_oct16<CW, QN, ROW>(ws_all, ws_off, scratch, l, k, rg);
+            off0 = -32 * rg.fbase[0]; off1 = 96 - 32 * rg.fbase[1]; off2 = 192 - 32 * rg.fbase[2];
+        } else {
+            tb_refill_oct<CW, QN, ROW>(ws_all, ws_off, scratch, l, c, k, rg);
+            off0 = 4 * (-8 * rg.fbase[0] - 4 * rg.qbase0);
+            off1 = 4 * (16 - 8 * rg.fbase[1] - 4 * (QN - 2));
+        }
     };
     auto fetch = [&](int l, int c, int k) {
-        const uint32_t row = ((uint32_t)k >> 3 << 5) + (uint32_t)(l == rg.l0 ? off0 : off1);
+        const int off = kLinWalkSpan == 16 ? (l == rg.l0 ? off0 : l == rg.l0 - 1 ? off1 : off2) : (l == rg.l0 ? off0 : off1);
+        const uint32_t row = ((uint32_t)k >> 3 << 5) + (uint32_t)off;
         const uint32_t w = *(LdsWord *)(cache + (((uint32_t)c >> 1 << 2) + row));
         return __builtin_amdgcn_ubfe(w, (((uint32_t)c & 1u) << 4) + 14u - (((uint32_t)k & 7u) << 1), 2u);
     };
@@ -263,11 +280,11 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
         const int l = (int)(__umul24((uint32_t)p, kMagic) >> 16);       // 24-bit multiplies: full rate
         const int c = p + __mul24(l, -CW);
         const int k = imax(kA + l + nis, 0);
-        if ((it & 7) == 7) {
+        if ((it & (kLinWalkSpan - 1)) == kLinWalkSpan - 1) {
             refill(l, c, k);
-            // banded stores (gact_lin.hpp LinBand): words are there for |di - dj| <= band.  The next eight moves change
-            // di - dj by eight at most: further out than band - 8 here, the walk gives up and its tile is run again with
-            // every block stored (band_lim = band - 8; negative: the tile stored everything)
+            // banded stores (gact_lin.hpp LinBand): words are there for |di - dj| <= band.  The moves up to the next refill
+            // change di - dj by their number at most: further out than band - kLinWalkSpan here, the walk gives up and its
+            // tile is run again with every block stored (band_lim = band - kLinWalkSpan; negative: the tile stored everything)
             redo = redo | ((band_lim >= 0) & ((unsigned)(nis - njs + band_lim) > (unsigned)(2 * band_lim)));
         }
         // the op and the bases of the cell just entered: three LDS reads in flight together.  The op is the next
@@ -313,7 +330,8 @@ __device__ __forceinline__ void walk_chain_lin(const uint32_t *ws, uint32_t *scr
 // what a walk is made of now (the words of a 200 x 200 window are 14 KB per tile, 43 MB per XCD in flight: they come
 // back from beyond the L2, ~3,500 clocks each time), and every team of the wave takes its refill at the same trip.
 constexpr int kLaTeam = 8;
-constexpr int kLaBandMargin = 12, kWalkBandMargin = 8;      // how far inside the stored band a walk must be when it refills (team / one lane)
+constexpr int kLaBandMargin = 12, kWalkBandMargin = 8;      // how far inside the stored band a walk must be when it refills (team / one lane;
+                                                            // the one-lane linear-gap walker: kLinWalkSpan)
 #ifndef GACT_WALK_SYNC_REFILL
 #define GACT_WALK_SYNC_REFILL 1
 #endif

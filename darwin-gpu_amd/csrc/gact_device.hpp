@@ -440,7 +440,7 @@ constexpr int kTbScratchWords = 18 * 4;      // dwords of LDS per walker (12 uin
 
 template <int CW> struct TbRegion {
     int l0;              // lane of the anchor column
-    int fbase[2];        // first cached flush block, for lane l0 and lane l0-1
+    int fbase[3];        // first cached flush block, for lane l0, lane l0-1 (and lane l0-2: tb_refill_oct16)
     int qbase0;          // first cached column quad of lane l0 (lane l0-1 always caches its last three)
 };
 
@@ -540,6 +540,46 @@ __device__ __forceinline__ void tb_refill_oct(const uint32_t *ws_all, uint32_t w
     u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
 #pragma unroll
     for (int n = 0; n < 8; n++) dst[n] = r[n];
+}
+
+// A region of SIXTEEN steps for the same words (round 4): the one-lane walker's time is its refills -- 46 round trips of
+// ~3,500 clocks per walk of 370 columns, 437 of the 478 clocks a step costs -- so it asks half as often for more.  Sixteen
+// moves from the anchor reach at most 16 columns to the left (CW >= 8: three lanes, l0 .. l0-2, both column octets of each)
+// and, in every one of those lanes, 16 stored steps back from the anchor's (three flush blocks): 3 x 3 x 2 = 18 uint4,
+// all in flight together, the kTbScratchWords the scratch already has.  Cache layout: [lane slot s][block b][octet o] uint4.
+template <int CW, int QN, int ROW>
+__device__ __forceinline__ void tb_refill_oct16(const uint32_t *ws_all, uint32_t ws_off, uint32_t *scratch, int l0, int k0,
+                                                TbRegion<CW> &rg)
+{
+    static_assert(QN == 2 && CW >= 8 && CW <= 16, "both column octets of three lanes cover sixteen columns to the left");
+    static_assert(kTbScratchWords >= 18 * 4, "18 uint4 of scratch");
+    constexpr int kOct = 16 * ROW, kBlk = 16 * QN * ROW;           // byte strides of a column octet, of a flush block
+    static_assert(kOct < 4096, "the octet stride is the load's immediate offset");
+    rg.l0 = l0;
+    rg.qbase0 = 0;
+    uint32_t a[9];
+#pragma unroll
+    for (int sl = 0; sl < 3; sl++) {
+        rg.fbase[sl] = imax(((k0 - sl) >> 3) - 2, 0);
+        const uint32_t base = ws_off + (uint32_t)(rg.fbase[sl] * kBlk + imax(l0 - sl, 0) * 16);
+        a[3 * sl] = base; a[3 * sl + 1] = base + kBlk; a[3 * sl + 2] = base + 2 * kBlk;
+    }
+    u32x4 r[18];
+    // (s_nop in every statement: the base may have just come out of a spill lane, see tb_refill_oct -- the compiler may put
+    //  such a reload in front of any of them)
+#pragma unroll
+    for (int n = 0; n < 9; n++)
+        asm volatile("s_nop 4\n\t"
+                     "global_load_dwordx4 %0, %2, %3 sc1\n\t"
+                     "global_load_dwordx4 %1, %2, %3 offset:%4 sc1"
+                     : "=&v"(r[2 * n]), "=&v"(r[2 * n + 1]) : "v"(a[n]), "s"(ws_all), "n"(kOct) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]),
+                   "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]), "+v"(r[16]), "+v"(r[17])
+                 :: "memory");
+    u32x4 *dst = reinterpret_cast<u32x4 *>(scratch);
+#pragma unroll
+    for (int n = 0; n < 18; n++) dst[n] = r[n];
 }
 
 // Pointer word formats (read by walk_chain, gact_chain.hpp):

@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
             L::walk_start(Rh, Qh, L::tile_tB(tB, sh), l0, c0, k0);
             // how far from the diagonal through (R, Q) a walk of this tile may be when it refills; -1: every block is there
             const int band_lim = ((L::kWalkFmt == 3 || L::kWalkFmt == 4) && (kp.band & 0xffff) > 0 && !(h ? pt.full[1] : pt.full[0]))
-                                     ? (kp.band & 0xffff) - (kTeamWalk ? kLaBandMargin : kWalkBandMargin) : -1;
+                                     ? (kp.band & 0xffff) - (kTeamWalk ? kLaBandMargin : L::kWalkFmt == 3 ? kLinWalkSpan : kWalkBandMargin) : -1;
             if constexpr (kTeamWalk && GACT_EXP_FAKE_WALK) {
                 // timing experiment only (results are wrong): no walk, every tile taken as a diagonal of `early` steps
                 wk.load(st[h]);

@@ -132,6 +132,8 @@ struct Slot {
     DevBuf<int> order;                   // ordered seeding: the run's candidates by length class, longest first (run_overlapped)
     hipStream_t aux_stream = nullptr;    // overlapped seeding: the second seed launch and the main launch behind it
     hipEvent_t aux_ev_a = nullptr, aux_ev_b = nullptr;
+    long merge_gen = -1;                 // which merged launch carried this slot's last run (Combiner::merged_launches then): its peers have the same
+    long merge_prev_gen = -1;            // ... and the one before that (two halves of a group that came apart have it in common)
     bool overlapped = false;             // the last run seeded while its main launch was running
     bool lane = false;                   // ... had a critical lane (a wide main launch beside the split one)
     // call combiner (Combiner below; all under its mutex)
@@ -236,7 +238,7 @@ struct Combiner {
     int window_us = 1000;             // GACT_HIP_COMBINE_US: how long the leader waits for the others at most
     int next_merge = 0;
     int n_merge = 0;
-    long merged_launches = 0, merged_runs = 0;
+    long merged_launches = 0, merged_runs = 0, rejoins = 0;
 };
 
 struct gact_hip_engine {
@@ -1212,7 +1214,7 @@ void gact_hip_destroy(gact_hip_engine *e)
 {
     if (!e) return;
     if (getenv("GACT_HIP_TRACE") && e->cb.merged_launches)
-        fprintf(stderr, "[gact_hip] combiner: %ld merged launches carried %ld runs\n", e->cb.merged_launches, e->cb.merged_runs);
+        fprintf(stderr, "[gact_hip] combiner: %ld merged launches carried %ld runs, %ld times a group that had come apart was joined again\n", e->cb.merged_launches, e->cb.merged_runs, e->cb.rejoins);
     (void)hipSetDevice(e->params.device_id);
     for (auto &sl : e->slots) {
         if (sl.stream) (void)hipStreamSynchronize(sl.stream);
@@ -1553,6 +1555,8 @@ static int launch_merged(gact_hip_engine *e, const std::vector<RunReq *> &batch)
         Slot &dst = e->slots[batch[k]->slot];
         HIP_TRY(hipStreamWaitEvent(dst.stream, ms.ev_ready, 0));
         dst.merged_into = m; dst.merged_callers = (int)batch.size();
+        dst.merge_prev_gen = dst.merge_gen;
+        dst.merge_gen = cb.merged_launches;
         dst.timed = true;
     }
     cb.merged_launches++; cb.merged_runs += (long)batch.size();
@@ -1593,10 +1597,23 @@ static int combined_submit(gact_hip_engine *e, int slot, int first, int n, int r
         //  group split 2 + 4 + 8 over its two calls printed 59 ms where 48 were due.  A peer that does not come back costs the
         //  long wait once: the next launch's members are the ones that did.)
         const bool had_peers = e->slots[slot].merged_into >= 0 && e->slots[slot].merged_callers > 1;
-        const auto deadline = clock::now() + std::chrono::microseconds((first_run || had_peers) ? 3 * cb.window_us : cb.window_us);
+        // (the peers of that launch are expected however long ago they called last: after a pause of the whole group -- the
+        //  reference's threads between their phases, a barrier -- the first arrivals found every other slot "stale", launched
+        //  at once with whoever had made it, and the two halves of the group then took turns for good: 4 + 4 runs per launch,
+        //  40 ms per step where 32 were due.  A peer that has left keeps its old number and is waited for once.)
+        const long my_gen = had_peers ? e->slots[slot].merge_gen : -1;
+        // (... and a group that did come apart joins again: the other half -- in flight on a launch of its own, the launch
+        //  before that shared with this thread -- is waited for, once, for as long as a launch may last: two halves taking
+        //  turns share the machine and need 40 ms a step each, for good; waiting for the other launch to end costs half of
+        //  that, once)
+        const long my_prev_gen = had_peers ? e->slots[slot].merge_prev_gen : -1;
+        auto deadline = clock::now() + std::chrono::microseconds((first_run || had_peers) ? 3 * cb.window_us : cb.window_us);
+        const auto rejoin_deadline = clock::now() + std::chrono::milliseconds(60);
+        bool rejoined = false;
         for (;;) {
             const auto now = clock::now();
             int expected = 0;
+            bool other_half_running = false;
             for (int k = 0; k < e->n_user; k++) {
                 const Slot &o = e->slots[k];
                 bool is_pending = false;
@@ -1607,15 +1624,27 @@ static int combined_submit(gact_hip_engine *e, int slot, int first, int n, int r
                     // be back in a moment (the other members of the launch this thread has just fetched from)
                     const Slot &src = o.merged_into >= 0 ? e->slots[o.merged_into] : o;
                     const hipEvent_t ev = o.merged_into >= 0 ? src.ev_ready : src.ev1;
-                    if (!ev || hipEventQuery(ev) != hipSuccess) { (void)hipGetLastError(); continue; }
-                } else if (!first_run && now - o.last_call >= std::chrono::milliseconds(3)) {
+                    if (!ev || hipEventQuery(ev) != hipSuccess) {
+                        (void)hipGetLastError();
+                        if (my_prev_gen >= 0 && o.merge_gen != my_gen && o.merge_prev_gen == my_prev_gen && o.merged_callers > 1) other_half_running = true;
+                        continue;
+                    }
+                } else if (!first_run && now - o.last_call >= std::chrono::milliseconds(3) && !(my_gen >= 0 && o.merge_gen == my_gen)) {
                     continue;
                 }
                 expected++;
             }
+            if (other_half_running && now < rejoin_deadline && (int)cb.pending.size() < gact::kMaxMerge) {
+                // its launch ends, its threads fetch and call again: from then on they are "expected" like any peer
+                rejoined = true;
+                deadline = std::max(deadline, now + std::chrono::microseconds(3 * cb.window_us));
+                cb.cv.wait_until(lk, now + std::chrono::microseconds(100));
+                continue;
+            }
             if (expected == 0 || now >= deadline || (int)cb.pending.size() >= gact::kMaxMerge) break;
             cb.cv.wait_until(lk, std::min(deadline, now + std::chrono::microseconds(50)));
         }
+        if (rejoined) cb.rejoins++;
         std::vector<RunReq *> batch;
         batch.swap(cb.pending);
         for (RunReq *r : batch) e->slots[r->slot].in_flight = true;

@@ -157,6 +157,63 @@ def test_overlapped_seeding_equals_the_plain_sequence():
     eng.close()
 
 
+def test_a_group_of_feeder_threads_that_came_apart_joins_again():
+    """Eight feeder threads with an eighth of ecoli10x each, all runs in one launch; then half of them is held back for one
+    step, so that the two halves launch apart -- and would go on taking turns, each launch with four runs, sharing the machine.
+    The leader of one half waits for the other half's launch once (the call combiner's re-join rule) and from then on every
+    launch carries all eight runs again; records as in the joint launches."""
+    import time
+    from conftest import workload_block
+    from gact_amd import engine
+    blk = workload_block("ecoli10x")
+    T = 8
+    eng = engine.Engine(n_slots=T)
+    _load(eng, blk.rs)
+    parts = []
+    for k in range(T):
+        f, r = blk.cf[k::T], blk.cr[k::T]
+        eng.candidates_upload(np.concatenate([f, r]), slot=k)
+        parts.append((len(f), len(r)))
+    gate = threading.Barrier(T)
+    first, last, merged_hist, errors = [None] * T, [None] * T, [[] for _ in range(T)], []
+
+    def feeder(k):
+        try:
+            nf, nr = parts[k]
+            def step():
+                eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=k)
+                rec = eng.candidates_fetch(nf + nr, slot=k).copy()
+                merged_hist[k].append(eng.last_run_stats(k)["merged_callers"])
+                return rec
+            gate.wait()
+            first[k] = step()                       # all together
+            step()
+            gate.wait()
+            if k >= T // 2:
+                time.sleep(0.012)                   # the second half misses this launch
+            for _ in range(8):
+                last[k] = step()
+        except Exception as err:
+            errors.append(err)
+            try:
+                gate.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=feeder, args=(k,)) for k in range(T)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert all(h[0] == T and h[1] == T for h in merged_hist), merged_hist          # joint launches first
+    assert any(h[2] < T for h in merged_hist), merged_hist                          # ... then apart
+    assert all(h[-1] == T and h[-2] == T for h in merged_hist), merged_hist         # ... and together again
+    for k in range(T):
+        assert last[k].tobytes() == first[k].tobytes()
+    eng.close()
+
+
 def test_the_critical_lane_changes_no_record(monkeypatch):
     """A run of 1-1.5 chains per tile slot on an idle engine has a wide main launch beside its split one, on a third of the
     blocks, and the split launch leaves it the longest chains (ChainQueues::leave_longest): a 30,000-candidate range of

@@ -708,7 +708,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                 // (measured on ecoli10x, 2.7 chains per tile slot: a run that size is bound by throughput, and a third of the
                 //  waves in the wide layout cost 12 % of that -- main launches 34-35 ms instead of 29.5-30.3; the lane is for
                 //  runs of fewer chains, below.  GACT_HIP_CRIT_LANE_ALWAYS=1 takes it here too.)
-                const bool lane = e->crit_lane && e->crit_lane_always && main2_blocks <= e->wide_lin_grid_blocks;
+                const bool lane = e->crit_lane && e->crit_lane_always && e->wide == 0 && main2_blocks <= e->wide_lin_grid_blocks;
                 auto kmain2 = lane ? gact::extend_p16_kernel<gact::WideLayoutLin, false, true> : kmain;
                 const int lane_tiles = main2_blocks * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
                 // seed launch A
@@ -825,7 +825,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
             const int narrow_slots0 = e->lin_grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
             // (GACT_HIP_LANE_BLOCKS=<n>: another size for the lane, the split launch takes the rest)
             const int lane_blocks = e->lane_blocks > 0 ? std::min(e->lane_blocks, e->lin_grid_blocks / 2) : e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3;
-            if (e->crit_lane && lin && !wide && !raw && !trace && !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 &&
+            if (e->crit_lane && e->wide == 0 && lin && !wide && !raw && !trace && !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 &&
                 !e->team_when_shared && count > narrow_slots && (count < narrow_slots0 + narrow_slots0 / 2 || e->crit_lane_always) &&
                 count <= 4 * narrow_slots0 && e->lin_grid_blocks >= 3 &&
                 lane_blocks <= e->wide_lin_grid_blocks) {

@@ -257,6 +257,8 @@ struct gact_hip_engine {
     int wide_blocks_per_cu = 0; // GACT_HIP_WIDE_BLOCKS_PER_CU: resident blocks per CU of the wide launch (default 2)
     bool crit_lane = true;      // GACT_HIP_NO_CRIT_LANE unset: a run of 1-1.5 chains per tile slot on an idle engine has a wide launch beside its split one
     int lane_blocks = 0;                // GACT_HIP_LANE_BLOCKS=<n>: blocks of the lane (default: a third of the resident blocks)
+    bool lane_small = false;            // GACT_HIP_LANE_SMALL=<f>: runs of fewer chains than tile slots, but at least f/2 per tile of the lane, take the
+    int lane_small_factor = 3;          //   lane + split launches instead of the all-wide launch (experiment; f defaults to 3)
     bool crit_lane_always = false;      // GACT_HIP_CRIT_LANE_ALWAYS=1: ... and larger runs (up to 4 chains per slot) too
     bool kernel_copies = true;  // GACT_HIP_SDMA_COPIES unset: candidate lists and records cross the bus in a kernel (bus_copy_kernel)
     bool shared_hint = true;    // GACT_HIP_NO_SHARED_HINT unset: a launch made while another slot is running does not pick the wide layout
@@ -784,7 +786,13 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
         const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
         // (the side lane's few chains are latency-bound whatever else runs)
-        const bool wide = C == 20 && e->wide >= 0 && (e->wide > 0 || (count <= narrow_slots && (!shared_machine || ln.stream != sl.stream)));
+        // (a run of fewer chains than tile slots but several per slot of the critical lane: the lane for its longest chains, one
+        //  wide wave per SIMD, and the split launch beside it for the rest -- GACT_HIP_LANE_SMALL, see the lane below)
+        const int lane_tiles_small = (e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3) * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
+        const bool lane_small = C == 20 && e->lane_small && e->crit_lane && e->wide == 0 && e->lin && e->split && !raw && !trace && !second_set &&
+                                !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 && count <= narrow_slots &&
+                                count >= e->lane_small_factor * lane_tiles_small / 2 && e->lin_grid_blocks >= 3;
+        const bool wide = C == 20 && e->wide >= 0 && !lane_small && (e->wide > 0 || (count <= narrow_slots && (!shared_machine || ln.stream != sl.stream)));
         using gact::extend_p16_kernel;
         const bool tg = e->tagged;
         const bool lin = e->lin && !raw && (wide || e->split);
@@ -809,7 +817,13 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // two waves per SIMD, not three: this launch lasts as long as its longest chain, and a wave advances a chain
         // at one instruction per ~11 cycles with one neighbour on its SIMD, ~15 with two (8 alone, but then half the
         // VALU idles): ONT-shape workload 150 ms -> 116 ms; one wave per SIMD: 132 ms
-        const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : 2;
+        // (round 4, the linear-gap wide launch: with more chains than TWO blocks per CU hold tile slots the launch is bound by
+        //  throughput either way, and two wide waves on a SIMD get little more through than one -- 0.19 ms an iteration each
+        //  against 0.108 -- while every chain advances that much slower: ONT shape alone 81.5-83.8 ms at two blocks per CU,
+        //  77.6-78.8 at one, 112 at three, profiles/r04/ont_wide_blocks_per_cu.txt.  Up to one block per CU of chains the grid
+        //  is that small anyway; in between -- every chain resident at two blocks -- two it stays.)
+        const int slots_at_two = 2 * e->prop.multiProcessorCount * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
+        const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : (lin && count > slots_at_two) ? 1 : 2;
         const int wide_cap = std::min(lin ? e->wide_lin_grid_blocks : e->grid_blocks, per_cu * e->prop.multiProcessorCount);
         const int wide_blocks = grid((count + 15) / 16, wide_cap);             // 4 tiles per wave
         // two waves per SIMD already saturate the DP code (DESIGN 5.0 "Resident waves"): a launch that shares the machine
@@ -826,7 +840,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
             // (GACT_HIP_LANE_BLOCKS=<n>: another size for the lane, the split launch takes the rest)
             const int lane_blocks = e->lane_blocks > 0 ? std::min(e->lane_blocks, e->lin_grid_blocks / 2) : e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3;
             if (e->crit_lane && e->wide == 0 && lin && !wide && !raw && !trace && !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 &&
-                !e->team_when_shared && count > narrow_slots && (count < narrow_slots0 + narrow_slots0 / 2 || e->crit_lane_always) &&
+                !e->team_when_shared && (count > narrow_slots || lane_small) && (count < narrow_slots0 + narrow_slots0 / 2 || e->crit_lane_always) &&
                 count <= 4 * narrow_slots0 && e->lin_grid_blocks >= 3 &&
                 lane_blocks <= e->wide_lin_grid_blocks) {
                 { int arc = ensure_aux_stream(sl); if (arc) return arc; }
@@ -1096,6 +1110,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->crit_lane = getenv("GACT_HIP_NO_CRIT_LANE") == nullptr;
     e->crit_lane_always = getenv("GACT_HIP_CRIT_LANE_ALWAYS") != nullptr;
     if (const char *v = getenv("GACT_HIP_LANE_BLOCKS")) e->lane_blocks = std::max(0, atoi(v));
+    if (const char *v = getenv("GACT_HIP_LANE_SMALL")) { e->lane_small = atoi(v) > 0; e->lane_small_factor = std::max(1, atoi(v)); }
     e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
     e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
     e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;

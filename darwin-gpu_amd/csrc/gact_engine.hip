@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>           // types of the RCCL entry points gact_gather.hpp looks up at run time (nothing is linked)
 
+#include <cerrno>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <unistd.h>

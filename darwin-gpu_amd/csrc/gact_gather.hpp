@@ -114,7 +114,11 @@ static int exchange_id(int rank, const char *path, int timeout_s, ncclUniqueId *
         if (fd < 0) return fail(GACT_HIP_EINVAL, "comm_create: cannot create '%s'", tmp.c_str());
         const bool wrote = write(fd, id, sizeof *id) == (ssize_t)sizeof *id && fsync(fd) == 0;
         close(fd);
-        const bool linked = wrote && link(tmp.c_str(), path) == 0;
+        bool linked = wrote && link(tmp.c_str(), path) == 0;
+        const int link_errno = errno;
+        // (a file system without hard links: look, then rename -- not atomic against another rank 0, but that is another job's
+        //  mistake to make, not this one's)
+        if (wrote && !linked && link_errno != EEXIST && access(path, F_OK) != 0) linked = rename(tmp.c_str(), path) == 0;
         unlink(tmp.c_str());
         if (!linked) return fail(GACT_HIP_EINVAL, "comm_create: '%s' exists already (an earlier job's?) or cannot be written", path);
         return 0;

@@ -214,6 +214,53 @@ def test_a_group_of_feeder_threads_that_came_apart_joins_again():
     eng.close()
 
 
+def test_feeder_threads_with_jitter_keep_their_records(oracle):
+    """seven threads, seven slots, fifteen runs each with random pauses of 0-6 ms in between (and one thread that leaves after
+    five): whatever groups the combiner forms, splits and joins again, every run returns its own list's records, and nobody waits
+    for long (each run of this size takes a few milliseconds)"""
+    import time
+    from gact_amd import engine, synth
+    rs = synth.simulate_reads(90000, n_reads=70, seed=61, mean_len=6000, sd_len=1500, min_len=1200, max_len=10000)
+    cf, cr = synth.synth_candidates(rs, seed=62, min_overlap=300, false_frac=0.15)
+    want_all = _oracle_records(oracle, rs, cf, cr)
+    T = 7
+    eng = engine.Engine(n_slots=T)
+    _load(eng, rs)
+    lists = []
+    for k in range(T):
+        f, r = cf[k::T], cr[k::T]
+        lists.append((f, r, np.concatenate([want_all[:len(cf)][k::T], want_all[len(cf):][k::T]])))
+        eng.candidates_upload(np.concatenate([f, r]), slot=k)
+    errors, slowest, merged_seen = [], [0.0] * T, [set() for _ in range(T)]
+
+    def feeder(k):
+        try:
+            rng = np.random.default_rng(1000 + k)
+            f, r, want = lists[k]
+            n = len(f) + len(r)
+            for rep in range(5 if k == 3 else 15):
+                time.sleep(float(rng.uniform(0, 0.006)))
+                t0 = time.perf_counter()
+                eng.candidates_run_mixed(n, rc_from=len(f), slot=k)
+                got = eng.candidates_fetch(n, slot=k)
+                slowest[k] = max(slowest[k], time.perf_counter() - t0)
+                merged_seen[k].add(eng.last_run_stats(k)["merged_callers"])
+                for fld in ("ab", "ae", "bb", "be", "score", "emitted", "first_tile_score", "n_tiles", "cells"):
+                    assert np.array_equal(got[fld], want[fld]), (k, rep, fld)
+        except Exception as err:
+            errors.append(err)
+
+    threads = [threading.Thread(target=feeder, args=(k,)) for k in range(T)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:2]
+    assert max(slowest) < 0.5, slowest                      # (no run sat in a collect window or a re-join wait for long)
+    assert any(len(m) > 1 or max(m) > 1 for m in merged_seen), merged_seen      # (some runs were merged)
+    eng.close()
+
+
 def test_the_critical_lane_changes_no_record(monkeypatch):
     """A run of 1-1.5 chains per tile slot on an idle engine has a wide main launch beside its split one, on a third of the
     blocks, and the split launch leaves it the longest chains (ChainQueues::leave_longest): a 30,000-candidate range of

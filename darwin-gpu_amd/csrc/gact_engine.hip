@@ -22,6 +22,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -33,6 +34,7 @@
 #include "gact_p16s.hpp"
 #include "gact_lin.hpp"
 #include "gact_aff.hpp"
+#include "gact_roles.hpp"
 #include "gact_big.hpp"
 #include "dsoft_device.hpp"
 
@@ -114,6 +116,17 @@ template <class T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// The figures of ONE merged launch: events and counters of its own, recorded / copied behind that launch and
+// never touched again, so that a caller that asks for its run's statistics after its fetch reads them whatever the merge
+// slot is doing by then (the slot's own events and counters are re-recorded as soon as its arrays are free).  Records are
+// pooled per engine; a caller's slot keeps the one of its last merged run alive.
+struct LaunchStats {
+    hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr, ev_done = nullptr;
+    int *h_counter = nullptr;            // pinned: 2 x kCounterInts ints (the lane's own, the side lane's)
+    bool two_phase = false, wide = false, lin = false, aff = false, overlapped = false, lane = false, side_used = false, roles = false;
+    int routed_raw = 0;
+};
+
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mid = nullptr;
@@ -137,12 +150,14 @@ struct Slot {
     long merge_prev_gen = -1;            // ... and the one before that (two halves of a group that came apart have it in common)
     bool overlapped = false;             // the last run seeded while its main launch was running
     bool lane = false;                   // ... had a critical lane (a wide main launch beside the split one)
+    bool roles = false;                  // ... ran its main launch(es) with DP waves and walker waves (gact_roles.hpp)
     // call combiner (Combiner below; all under its mutex)
     std::thread::id last_thread;         // who called last for this slot, and when: is a run from it likely soon?
     std::chrono::steady_clock::time_point last_call{};
     bool in_flight = false;              // a run has been launched and not been fetched / waited for
     int merged_into = -1;                // index of the merge slot the last run of this slot was part of (-1: its own launches)
     int merged_callers = 1;              // how many callers' runs that launch carried
+    std::shared_ptr<LaunchStats> merged_stats;   // ... and that launch's own figures (written by the leader before the run counts as launched)
     hipEvent_t ev_ready = nullptr;       // candidates of this slot are in place (recorded before a merged gather)
     int routed_raw = 0;                  // how many candidates the last run aligned from raw bytes beside the 2-bit launches
     DevBuf<gact::ChainState> chain_states;
@@ -240,6 +255,7 @@ struct Combiner {
     int next_merge = 0;
     int n_merge = 0;
     long merged_launches = 0, merged_runs = 0, rejoins = 0;
+    std::vector<std::shared_ptr<LaunchStats>> stats_pool;      // (the leader's: one leader at a time)
 };
 
 struct gact_hip_engine {
@@ -276,6 +292,8 @@ struct gact_hip_engine {
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
     int seed_lin_grid_blocks = 0;       // ... of its linear-gap form (3)
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
+    bool roles = true;          // GACT_HIP_NO_ROLES unset: the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
+    int role_grid_blocks = 0;   // ... and its persistent grid (blocks of kRoleThreads)
     int aff_grid_blocks = 0;    // ... of the drifted affine split launch (two blocks per CU)
     int wide_lin_grid_blocks = 0;       // ... of the linear-gap wide launch
     gact::P16Consts kc;
@@ -628,6 +646,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     sl.routed_raw = 0;
     sl.overlapped = false;
     sl.lane = false;
+    sl.roles = false;
     // Is another slot of this engine still running?  Then this launch shares the machine (feeder threads, steps in
     // flight) and what counts is throughput: the wide layout -- faster per chain, slower per cell, made for a launch
     // that has the CUs to itself and lasts as long as its longest chain -- is not taken on its own account.
@@ -702,16 +721,20 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                 //  rest in launch A)
                 const int nA = std::max(std::min(count, main1_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots),
                                         count - 2 * narrow_slots0);
-                const size_t ws_split = ws_words_for(e, main1_blocks);
+                // (the role launch, gact_roles.hpp: blocks of six waves, its own workspace layout)
+                const bool roles = e->roles;
+                const int role1_blocks = e->role_grid_blocks * 2 / 3, role2_blocks = e->role_grid_blocks - role1_blocks;
+                const size_t ws_split = roles ? gact::role_ws_words<gact::SplitLayoutLin<7, 13>>(role1_blocks) : ws_words_for(e, main1_blocks);
                 auto seed_blocks_for = [&](int cnt, int cap) { return std::max(1, std::min(((cnt + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave) + 3) / 4, cap)); };
                 auto kseed = gact::seed_p16_kernel<20, false, 1>;
                 auto kmain = gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>;
+                auto kmain_roles = gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, true>;
                 // the critical lane (ChainQueues::leave_longest): main launch 2 in the wide layout -- its third of the blocks
                 // holds 16 tiles a block -- and main launch 1 leaves it that many of the longest chains
                 // (measured on ecoli10x, 2.7 chains per tile slot: a run that size is bound by throughput, and a third of the
                 //  waves in the wide layout cost 12 % of that -- main launches 34-35 ms instead of 29.5-30.3; the lane is for
                 //  runs of fewer chains, below.  GACT_HIP_CRIT_LANE_ALWAYS=1 takes it here too.)
-                const bool lane = e->crit_lane && e->crit_lane_always && e->wide == 0 && main2_blocks <= e->wide_lin_grid_blocks;
+                const bool lane = !roles && e->crit_lane && e->crit_lane_always && e->wide == 0 && main2_blocks <= e->wide_lin_grid_blocks;
                 auto kmain2 = lane ? gact::extend_p16_kernel<gact::WideLayoutLin, false, true> : kmain;
                 const int lane_tiles = main2_blocks * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
                 // seed launch A
@@ -741,19 +764,27 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                     q2.more_count = s2.bucket_count; q2.more_pop = s2.bucket_pop; q2.more_live = s2.live;
                 }
                 if (count > nA) {
-                    hipLaunchKernelGGL(kmain2, dim3(main2_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
-                                       same_file, sl.overlaps.p, q2, ln.d_ws + ws_split);
+                    if (roles)
+                        hipLaunchKernelGGL(kmain_roles, dim3(role2_blocks), dim3(gact::kRoleThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
+                                           same_file, sl.overlaps.p, q2, ln.d_ws + ws_split);
+                    else
+                        hipLaunchKernelGGL(kmain2, dim3(main2_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
+                                           same_file, sl.overlaps.p, q2, ln.d_ws + ws_split);
                     HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
                 // main launch 1: set 1, then set 2
                 gact::ChainQueues q1 = q2;
                 if (lane && count > nA) q1.leave_longest = lane_tiles;
-                hipLaunchKernelGGL(kmain, dim3(main1_blocks), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr,
-                                   same_file, sl.overlaps.p, q1, ln.d_ws);
+                if (roles)
+                    hipLaunchKernelGGL(kmain_roles, dim3(role1_blocks), dim3(gact::kRoleThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr,
+                                       same_file, sl.overlaps.p, q1, ln.d_ws);
+                else
+                    hipLaunchKernelGGL(kmain, dim3(main1_blocks), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr,
+                                       same_file, sl.overlaps.p, q1, ln.d_ws);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
-                if (first_pass) { sl.wide = false; sl.lin = true; sl.lane = lane && count > nA; }
+                if (first_pass) { sl.wide = false; sl.lin = true; sl.lane = lane && count > nA; sl.roles = roles; }
                 sl.overlapped = true;
                 return 0;
             }
@@ -798,7 +829,9 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         const bool tg = e->tagged;
         const bool lin = e->lin && !raw && (wide || e->split);
         const bool aff = e->aff && !raw && !wide && C == 20;
-        if (first_pass) { sl.wide = wide; sl.lin = lin; sl.aff = aff; }
+        // the split linear-gap launch with DP waves and walker waves (gact_roles.hpp)
+        const bool roles = C == 20 && e->roles && lin && !wide && !(shared_machine && ln.stream == sl.stream && e->team_when_shared);
+        if (first_pass) { sl.wide = wide; sl.lin = lin; sl.aff = aff; sl.roles = roles; }
         auto km = lin ? (wide ? extend_p16_kernel<gact::WideLayoutLin, false>
                               : (shared_machine && ln.stream == sl.stream && e->team_when_shared)
                                     ? extend_p16_kernel<gact::SplitLayoutLinTeam<7, 13>, false>
@@ -840,7 +873,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
             const int narrow_slots0 = e->lin_grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
             // (GACT_HIP_LANE_BLOCKS=<n>: another size for the lane, the split launch takes the rest)
             const int lane_blocks = e->lane_blocks > 0 ? std::min(e->lane_blocks, e->lin_grid_blocks / 2) : e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3;
-            if (e->crit_lane && e->wide == 0 && lin && !wide && !raw && !trace && !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 &&
+            if (!roles && e->crit_lane && e->wide == 0 && lin && !wide && !raw && !trace && !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 &&
                 !e->team_when_shared && (count > narrow_slots || lane_small) && (count < narrow_slots0 + narrow_slots0 / 2 || e->crit_lane_always) &&
                 count <= 4 * narrow_slots0 && e->lin_grid_blocks >= 3 &&
                 lane_blocks <= e->wide_lin_grid_blocks) {
@@ -861,6 +894,18 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
                 HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
                 if (first_pass) sl.lane = true;
                 return 0;
+            }
+        }
+        if constexpr (C == 20) {
+            if (roles) {
+                // a block holds kRoleDp waves x 4 groups x 2 tiles x 2 banks; with fewer chains than that the blocks are spread
+                // over the machine one bank full each before the second banks fill
+                const int per_bank = gact::kRoleDp * gact::kGroupsPerWave * gact::kSlots;
+                const int role_blocks = grid((count + per_bank - 1) / per_bank, e->role_grid_blocks);
+                hipLaunchKernelGGL((gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(role_blocks), dim3(gact::kRoleThreads), 0,
+                                   ln.stream, kp, e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws);
+                HIP_TRY(hipGetLastError());
+                return traced(ln, "main launch (2-bit, DP + walker waves)", role_blocks, count);
             }
         }
         hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks_now)), dim3(gact::kBlockThreads), 0, ln.stream, kp,
@@ -1118,6 +1163,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->side_lane = getenv("GACT_HIP_NO_SIDE_LANE") == nullptr;
     e->shared_hint = getenv("GACT_HIP_NO_SHARED_HINT") == nullptr;
     e->overlap_seed = getenv("GACT_HIP_NO_OVERLAP") == nullptr;
+    e->roles = getenv("GACT_HIP_NO_ROLES") == nullptr;
     e->team_when_shared = getenv("GACT_HIP_TEAM_WHEN_SHARED") != nullptr;
     e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
     if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
@@ -1192,6 +1238,19 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         }
     }
     if (!e->lin) e->wide_lin_grid_blocks = e->grid_blocks;
+    e->role_grid_blocks = 0;
+    if (e->lin && e->split && e->C == 20 && e->roles) {
+        using RL = gact::SplitLayoutLin<7, 13>;
+        int rb = 0, rb2 = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&rb, gact::extend_roles_kernel<RL, false>, gact::kRoleThreads, 0) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&rb2, gact::extend_roles_kernel<RL, true>, gact::kRoleThreads, 0) != hipSuccess) {
+            delete e;
+            return fail(GACT_HIP_EDEVICE, "hipOccupancyMaxActiveBlocksPerMultiprocessor failed");
+        }
+        e->role_grid_blocks = std::max(1, std::min(rb, rb2)) * e->prop.multiProcessorCount;
+        if (const char *v = getenv("GACT_HIP_ROLE_BLOCKS")) e->role_grid_blocks = std::max(1, std::min(atoi(v), e->role_grid_blocks));
+    }
+    e->roles = e->role_grid_blocks > 0;
     e->aff_grid_blocks = e->grid_blocks;
     if (e->aff) {
         int ab = 0;
@@ -1205,8 +1264,20 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     if (p->max_blocks > 0) {                // a small engine (gact_hip_params.max_blocks): every persistent grid capped, the workspace with them
         for (int *g : {&e->grid_blocks, &e->seed_grid_blocks, &e->seed_lin_grid_blocks, &e->lin_grid_blocks, &e->wide_lin_grid_blocks, &e->aff_grid_blocks})
             *g = std::max(1, std::min(*g, (int)p->max_blocks));
+        // (a role block is six waves where the others are four)
+        if (e->roles) e->role_grid_blocks = std::max(1, std::min(e->role_grid_blocks, (int)p->max_blocks * 4 / (gact::kRoleDp + 1)));
     }
     e->ws_words_total = ws_words_for(std::max(std::max(e->grid_blocks, e->aff_grid_blocks), std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
+    if (e->roles) {
+        // the role launch lays its pointer words out by wave and bank (gact_roles.hpp); overlapped seeding puts two thirds of
+        // its blocks in front of a seed launch's and a main launch's share of the workspace
+        using RL = gact::SplitLayoutLin<7, 13>;
+        const int r1 = e->role_grid_blocks * 2 / 3, r2 = e->role_grid_blocks - r1;
+        const size_t need = std::max(gact::role_ws_words<RL>(e->role_grid_blocks),
+                                     gact::role_ws_words<RL>(r1) + std::max(gact::role_ws_words<RL>(r2), ws_words_for(e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3)));
+        if ((need + 64) * sizeof(uint32_t) >= (1ull << 32)) { e->roles = false; e->role_grid_blocks = 0; }
+        else e->ws_words_total = std::max(e->ws_words_total, need);
+    }
     if (big) {
         // one pointer matrix per wave (1 MB at 16 columns per lane, 4 MB at 32): at most 2 GiB per slot, two blocks per CU
         const size_t per_block = (gact::kBlockThreads / 64) * (e->big_cb == 16 ? gact::BigGeom<16>::kWsBytes : gact::BigGeom<32>::kWsBytes);
@@ -1265,6 +1336,15 @@ void gact_hip_destroy(gact_hip_engine *e)
             else (void)hipStreamDestroy(sl.stream);
         }
     }
+    for (Slot &sl : e->slots) sl.merged_stats.reset();
+    for (auto &r : e->cb.stats_pool) {
+        if (r->ev0) (void)hipEventDestroy(r->ev0);
+        if (r->ev_mid) (void)hipEventDestroy(r->ev_mid);
+        if (r->ev1) (void)hipEventDestroy(r->ev1);
+        if (r->ev_done) (void)hipEventDestroy(r->ev_done);
+        if (r->h_counter) (void)hipHostFree(r->h_counter);
+    }
+    e->cb.stats_pool.clear();
     for (auto &s : e->sets) s.release();
     e->dsoft.release_index();
     e->dsoft.release_scratch();
@@ -1556,9 +1636,41 @@ static int launch_merged(gact_hip_engine *e, const std::vector<RunReq *> &batch)
     }
     if (reserve_candidates(ms, (size_t)total)) return fail(GACT_HIP_ENOMEM, "device allocation failed (merged run of %d candidates)", total);
     ms.n_cands = (size_t)total;
+    // this launch's own statistics record: a pooled one nobody refers to any more, else a new one
+    std::shared_ptr<LaunchStats> rec;
+    for (auto &r : cb.stats_pool) if (r.use_count() == 1) { rec = r; break; }
+    if (!rec) {
+        rec = std::make_shared<LaunchStats>();
+        if (hipEventCreate(&rec->ev0) != hipSuccess || hipEventCreate(&rec->ev_mid) != hipSuccess || hipEventCreate(&rec->ev1) != hipSuccess ||
+            hipEventCreateWithFlags(&rec->ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void **)&rec->h_counter, 2 * kCounterInts * sizeof(int), hipHostMallocDefault) != hipSuccess)
+            return fail(GACT_HIP_ENOMEM, "merged run: statistics record");
+        cb.stats_pool.push_back(rec);
+    }
+    // (launch_run records the slot's ev0 / ev_mid / ev1: for this launch they are the record's)
+    std::swap(ms.ev0, rec->ev0); std::swap(ms.ev_mid, rec->ev_mid); std::swap(ms.ev1, rec->ev1);
+    struct SwapBack { Slot &ms; LaunchStats &r; ~SwapBack() { std::swap(ms.ev0, r.ev0); std::swap(ms.ev_mid, r.ev_mid); std::swap(ms.ev1, r.ev1); } };
     hipLaunchKernelGGL(gact::gather_kernel, dim3(std::max(1, std::min((total + 255) / 256, 2048))), dim3(256), 0, ms.stream, segs, ms.cands.p, total);
     HIP_TRY(hipGetLastError());
-    if ((rc = launch_run(e, ms, 0, total, gact::kCompInCand, batch[0]->same_file, strands))) return rc;
+    {
+        SwapBack back{ms, *rec};
+        if ((rc = launch_run(e, ms, 0, total, gact::kCompInCand, batch[0]->same_file, strands))) return rc;
+    }
+    rec->two_phase = ms.two_phase; rec->wide = ms.wide; rec->lin = ms.lin; rec->aff = ms.aff; rec->overlapped = ms.overlapped;
+    rec->lane = ms.lane; rec->side_used = ms.side_used; rec->routed_raw = ms.routed_raw; rec->roles = ms.roles;
+    if (ms.two_phase) {
+        // the counters as this launch leaves them, into the record's pinned array (a kernel copy: see bus_copy)
+        void *hc = device_view(rec->h_counter);
+        if (hc) {
+            if ((rc = bus_copy(ms.stream, ms.d_counter, hc, kCounterInts * sizeof(int)))) return rc;
+            if (ms.side_used && (rc = bus_copy(ms.stream, ms.side_counter, (char *)hc + kCounterInts * sizeof(int), kCounterInts * sizeof(int)))) return rc;
+        } else {
+            HIP_TRY(hipMemcpyAsync(rec->h_counter, ms.d_counter, kCounterInts * sizeof(int), hipMemcpyDeviceToHost, ms.stream));
+            if (ms.side_used) HIP_TRY(hipMemcpyAsync(rec->h_counter + kCounterInts, ms.side_counter, kCounterInts * sizeof(int), hipMemcpyDeviceToHost, ms.stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(rec->ev_done, ms.stream));
+    HIP_TRY(hipEventRecord(ms.ev1, ms.stream));          // ("is this slot still running?" is asked of the slot's own event)
     // every caller's records back into its own array, and its stream behind that
     for (size_t k = 0; k < batch.size(); k++) {
         const RunReq &r = *batch[k];
@@ -1571,6 +1683,7 @@ static int launch_merged(gact_hip_engine *e, const std::vector<RunReq *> &batch)
         Slot &dst = e->slots[batch[k]->slot];
         HIP_TRY(hipStreamWaitEvent(dst.stream, ms.ev_ready, 0));
         dst.merged_into = m; dst.merged_callers = (int)batch.size();
+        dst.merged_stats = rec;
         dst.merge_prev_gen = dst.merge_gen;
         dst.merge_gen = cb.merged_launches;
         dst.timed = true;
@@ -1855,8 +1968,16 @@ int gact_hip_last_kernel_ms(gact_hip_engine *e, int slot, float *ms)
     if (rc) return rc;
     if (!ms) return fail(GACT_HIP_EINVAL, "ms is NULL");
     if (!e->slots[slot].timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
-    Slot &sl = e->slots[slot].merged_into >= 0 ? e->slots[e->slots[slot].merged_into] : e->slots[slot];
     if ((rc = set_device(e))) return rc;
+    if (e->slots[slot].merged_into >= 0) {
+        // a merged run: the launch's own record (the merge slot's events may be another launch's by now)
+        const std::shared_ptr<LaunchStats> rec = e->slots[slot].merged_stats;
+        if (!rec) return fail(GACT_HIP_EINVAL, "slot %d: no statistics of its merged run", slot);
+        HIP_TRY(hipEventSynchronize(rec->ev1));
+        HIP_TRY(hipEventElapsedTime(ms, rec->ev0, rec->ev1));
+        return 0;
+    }
+    Slot &sl = e->slots[slot];
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(ms, sl.ev0, sl.ev1));
     return 0;
@@ -1868,14 +1989,47 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     if (rc) return rc;
     if (!st) return fail(GACT_HIP_EINVAL, "stats is NULL");
     if (!e->slots[slot].timed) return fail(GACT_HIP_EINVAL, "no kernel has been launched on slot %d", slot);
-    // a run that was merged with other callers' runs: the figures of that launch (the merge slot's last one)
-    const int merged_callers = e->slots[slot].merged_into >= 0 ? e->slots[slot].merged_callers : 1;
-    Slot &sl = e->slots[slot].merged_into >= 0 ? e->slots[e->slots[slot].merged_into] : e->slots[slot];
     if ((rc = set_device(e))) return rc;
     memset(st, 0, sizeof *st);
-    st->merged_callers = merged_callers;
+    if (e->slots[slot].merged_into >= 0) {
+        // a run that was merged with other callers' runs: the figures of THAT launch, from its own immutable record -- the
+        // merge slot's events and counters are re-recorded as soon as another leader takes the slot
+        const std::shared_ptr<LaunchStats> rec = e->slots[slot].merged_stats;
+        if (!rec) return fail(GACT_HIP_EINVAL, "slot %d: no statistics of its merged run", slot);
+        st->merged_callers = e->slots[slot].merged_callers;
+        st->overlapped_seeding = rec->overlapped ? 1 : 0;
+        st->critical_lane = rec->lane ? 1 : 0;
+        st->role_waves = rec->roles ? 1 : 0;
+        HIP_TRY(hipEventSynchronize(rec->ev_done));
+        HIP_TRY(hipEventElapsedTime(&st->total_ms, rec->ev0, rec->ev1));
+        st->main_ms = st->total_ms;
+        st->packed16 = rec->two_phase ? (rec->wide ? 3 : e->split ? 2 : 1) : 0;
+        st->seed_packed16 = (rec->two_phase && e->seed16) ? 1 : 0;
+        st->tagged_pointers = (rec->two_phase && e->tagged) ? 1 : 0;
+        st->linear_gap = (rec->two_phase && rec->lin) ? 1 : (rec->two_phase && rec->aff) ? 2 : 0;
+        st->raw_candidates = rec->routed_raw;
+        if (rec->two_phase) {
+            HIP_TRY(hipEventElapsedTime(&st->seed_ms, rec->ev0, rec->ev_mid));
+            HIP_TRY(hipEventElapsedTime(&st->main_ms, rec->ev_mid, rec->ev1));
+            const int *c = rec->h_counter;
+            for (int b = 0; b < gact::kBuckets; b++) st->handed_off += c[8 + b] + c[kMoreCount + b];
+            memcpy(&st->seed_cells, &c[2], sizeof(int64_t));
+            st->band_redos = c[6];
+            if (rec->side_used) {
+                const int *cs = rec->h_counter + kCounterInts;
+                for (int b = 0; b < gact::kBuckets; b++) st->handed_off += cs[8 + b];
+                int64_t sc = 0;
+                memcpy(&sc, &cs[2], sizeof(int64_t));
+                st->seed_cells += sc;
+            }
+        }
+        return 0;
+    }
+    Slot &sl = e->slots[slot];
+    st->merged_callers = 1;
     st->overlapped_seeding = sl.overlapped ? 1 : 0;
     st->critical_lane = sl.lane ? 1 : 0;
+    st->role_waves = sl.roles ? 1 : 0;
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
     st->main_ms = st->total_ms;
@@ -1946,6 +2100,12 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates)
                                    e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
                 hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>), dim3(1), dim3(gact::kBlockThreads), 0, st,
                                    e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q2, sl.d_ws);
+                if (e->roles) {
+                    hipLaunchKernelGGL((gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(1), dim3(gact::kRoleThreads), 0, st,
+                                       e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
+                    hipLaunchKernelGGL((gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, true>), dim3(1), dim3(gact::kRoleThreads), 0, st,
+                                       e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q2, sl.d_ws);
+                }
                 HIP_TRY(hipGetLastError());
             }
             HIP_TRY(hipStreamSynchronize(sl.stream));

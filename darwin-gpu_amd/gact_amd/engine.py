@@ -49,7 +49,7 @@ class RunStats(C.Structure):
                 ("tagged_pointers", C.c_int32), ("linear_gap", C.c_int32), ("seed_cells", C.c_int64),
                 ("raw_candidates", C.c_int32), ("band_redos", C.c_int32),
                 ("merged_callers", C.c_int32), ("overlapped_seeding", C.c_int32),
-                ("critical_lane", C.c_int32), ("reserved_", C.c_int32)]
+                ("critical_lane", C.c_int32), ("role_waves", C.c_int32)]
 
 
 class DsoftParams(C.Structure):
@@ -386,13 +386,15 @@ class Engine:
     def last_run_stats(self, slot=0):
         st = RunStats()
         self._check(self.L.gact_hip_last_run_stats(self.h, slot, C.byref(st)))
+        if st.band_redos & (1 << 30):
+            raise GactHipError("the role launch's watchdog fired: a DP wave went on without its walker's results (records are wrong)")
         return {"total_ms": st.total_ms, "seed_ms": st.seed_ms, "main_ms": st.main_ms,
                 "packed16": bool(st.packed16), "layout": ("int32", "packed16-uniform", "packed16-split", "packed16-wide")[st.packed16],
                 "seed_layout": "packed16" if st.seed_packed16 else "int32",
                 "tagged_pointers": bool(st.tagged_pointers), "linear_gap": st.linear_gap == 1, "affine_drift": st.linear_gap == 2,
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells, "raw_candidates": st.raw_candidates,
                 "band_redos": st.band_redos, "merged_callers": st.merged_callers, "overlapped_seeding": bool(st.overlapped_seeding),
-                "critical_lane": bool(st.critical_lane)}
+                "critical_lane": bool(st.critical_lane), "role_waves": bool(st.role_waves)}
 
     def measure_valu_rate(self):
         v = C.c_double()

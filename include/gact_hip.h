@@ -286,7 +286,8 @@ typedef struct {
                                            alone and main_ms holds the rest */
     int32_t critical_lane;              /* 1: beside the split main launch a wide one ran on a third of the blocks and took the
                                            longest chains (runs of 1-4 chains per tile slot on an otherwise idle engine) */
-    int32_t reserved_;
+    int32_t role_waves;                 /* 1: the split linear-gap main launch ran as DP waves + walker waves (the traceback walk of a
+                                           tile on another wave while its DP wave runs the pass of a second bank of tiles) */
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
 

@@ -67,9 +67,17 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
             sq = next(v for k, v in d["sq"].items() if k.startswith("extend"))
             wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if k.startswith("extend") and "WRITE_SIZE" in v)
             rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if k.startswith("extend") and "FETCH_SIZE" in v)
-            return {"source": os.path.relpath(path, here), "insts_valu": sq["SQ_INSTS_VALU"],
-                    "gui_active": sq["GRBM_GUI_ACTIVE"], "write_kib": wr, "fetch_kib": rd,
-                    "profiled_kernel_ms": b["kernel_ms"]}
+            out = {"source": os.path.relpath(path, here), "insts_valu": sq["SQ_INSTS_VALU"],
+                   "gui_active": sq["GRBM_GUI_ACTIVE"], "write_kib": wr, "fetch_kib": rd,
+                   "profiled_kernel_ms": b["kernel_ms"]}
+            # the seed launch of the same passes (since round 5: its own roofline block)
+            try:
+                sd = next(v for k, v in d["sq"].items() if k.startswith("seed"))
+                out["seed"] = {"insts_valu": sd["SQ_INSTS_VALU"], "gui_active": sd["GRBM_GUI_ACTIVE"],
+                               "profiled_kernel_ms": b.get("seed_kernel_ms"), "cells": b.get("seed_kernel_cells")}
+            except StopIteration:
+                pass
+            return out
         except (OSError, KeyError, StopIteration, ValueError):
             continue
     return None
@@ -108,11 +116,24 @@ def pmc_default_lookup(workload_name, candidates, cells_per_step):
 # and pointers are needed only inside the window a non-first tile's traceback can reach: early x early of
 # tile x tile cells (align.cpp:205), 0.39 at the reference's 320 / 120.  Nothing else is counted: no wavefront
 # skew, no loads, no traceback walk, no chain bookkeeping -- those are what `frac` is there to expose.
-def floor_slots_per_cell(linear, tile, early):
-    score, pointer = (5, 3) if linear else (11, 11)
+def floor_slots_per_cell(linear, tile, early, affine_drift=False):
+    # (the drifted affine pass, gact_aff.hpp:27,37: 7 instructions per cell pair for the scores -- 8 where mismatch < gap_extend --
+    #  and 8 more where pointers are made; priced at 7.5 + 8.  Round 1's tagged affine pass, what the uniform / wide / raw-byte
+    #  launches still run: 11 + 11)
+    score, pointer = (5, 3) if linear else (7.5, 8) if affine_drift else (11, 11)
     window = (min(early, tile) / tile) ** 2
     return (score + pointer * window) / 2.0, {"score_ops_per_cell_pair": score, "pointer_ops_per_cell_pair": pointer,
                                               "pointer_window_fraction": round(window, 4)}
+
+
+# the seed launch: first tiles -- arg-max and pointers of the WHOLE tile (align.cpp:173-177, traceback from the arg-max) -- so
+# every cell pays the pointer instructions and the arg-max key: linear gaps 5 + 3 + 3 (v_pk_mad key, v_pk_max, and the fold's
+# share) per cell pair, affine 7.5 + 8 + 3
+def seed_floor_slots_per_cell(linear):
+    return ((5 + 3 + 3) if linear else (7.5 + 8 + 3)) / 2.0
+
+
+PMC_MAX_DRIFT = 0.08         # a committed PMC pass whose kernel time is further than this from the live one is not quoted
 
 
 def main_kernel_name(st):
@@ -123,6 +144,8 @@ def main_kernel_name(st):
     if st.get("linear_gap"):            # linear gap scoring: the drifted pass (gact_lin.hpp)
         name = {"extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayoutLin<7,13>>",
                 "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutLin>"}[name]
+        if st.get("role_waves"):        # DP waves + walker waves (gact_roles.hpp)
+            name = name.replace("extend_p16_kernel", "extend_roles_kernel")
     elif st.get("affine_drift"):        # the drifted affine pass (gact_aff.hpp), split layout
         name = "extend_p16_kernel<SplitLayoutAff<7,13>>"
     elif st["tagged_pointers"]:         # pointer phase on tagged scores: the layouts' TAG variants
@@ -132,11 +155,17 @@ def main_kernel_name(st):
     return name
 
 
+def pmc_within_drift(pmc, k_ms):
+    """a committed PMC pass is quoted only when the kernel time it was taken at is within PMC_MAX_DRIFT of the live one"""
+    prof = pmc.get("profiled_kernel_ms")
+    return bool(prof) and abs(prof - k_ms) <= PMC_MAX_DRIFT * k_ms
+
+
 def short_roofline(st, k_ms, main_cells, info, workload_name, tile, early):
-    """roofline of a side configuration's main launch, the headline's figures in short"""
+    """roofline of a configuration's main launch, the headline's figures in short"""
     kernel = main_kernel_name(st)
     linear = bool(st.get("linear_gap"))
-    floor, _ = floor_slots_per_cell(linear, tile, early)
+    floor, _ = floor_slots_per_cell(linear, tile, early, affine_drift=bool(st.get("affine_drift")))
     peak = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
     achieved = floor * main_cells / (k_ms * 1e-3) / 1e12
     out = {"bound": "valu", "kernel": kernel, "kernel_ms": round(k_ms, 3), "kernel_cells": int(main_cells),
@@ -145,9 +174,34 @@ def short_roofline(st, k_ms, main_cells, info, workload_name, tile, early):
            "valu_issue_utilisation": None, "executed_slots_per_cell": None, "traffic": None, "source": None}
     pmc = pmc_lookup(workload_name, "dsoft", kernel, main_cells)
     if pmc:
-        out["executed_slots_per_cell"] = round(pmc["insts_valu"] * 64.0 / main_cells, 3)
-        out["valu_issue_utilisation"] = round(pmc["insts_valu"] * float(ISSUE_CYCLES) / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0), 4)
-        out["traffic"] = int((pmc["write_kib"] + FETCH_SIZE_CORRECTION * pmc["fetch_kib"]) * 1024)
+        out["profiled_kernel_ms"] = pmc["profiled_kernel_ms"]
+        out["kernel_ms_drift"] = round(k_ms / pmc["profiled_kernel_ms"] - 1.0, 4) if pmc["profiled_kernel_ms"] else None
+        if pmc_within_drift(pmc, k_ms):
+            out["executed_slots_per_cell"] = round(pmc["insts_valu"] * 64.0 / main_cells, 3)
+            out["valu_issue_utilisation"] = round(pmc["insts_valu"] * float(ISSUE_CYCLES) / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0), 4)
+            out["traffic"] = int((pmc["write_kib"] + FETCH_SIZE_CORRECTION * pmc["fetch_kib"]) * 1024)
+            out["source"] = pmc["source"]
+        else:
+            out["source"] = "%s refused: taken at %.2f ms, this run %.2f ms (more than %d %% apart)" % (
+                pmc["source"], pmc["profiled_kernel_ms"] or 0.0, k_ms, int(PMC_MAX_DRIFT * 100))
+    return out
+
+
+def seed_roofline(st, seed_ms, seed_cells, info, pmc):
+    """the seed launch (first tiles: arg-max + pointers of the whole tile) against the same issue peak"""
+    linear = bool(st.get("linear_gap"))
+    floor = seed_floor_slots_per_cell(linear)
+    peak = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
+    achieved = floor * seed_cells / max(seed_ms * 1e-3, 1e-9) / 1e12
+    out = {"bound": "valu", "kernel": {"packed16": "seed_p16_kernel<20>", "int32": "extend_kernel<20>"}[st["seed_layout"]],
+           "kernel_ms": round(seed_ms, 3), "kernel_cells": int(seed_cells), "floor_slots_per_cell": round(floor, 3),
+           "achieved": round(achieved, 3), "peak": round(peak, 3), "unit": "T lane-op slots/s", "frac": round(achieved / peak, 4),
+           "gcups": round(seed_cells / max(seed_ms * 1e-3, 1e-9) / 1e9, 1),
+           "valu_issue_utilisation": None, "executed_slots_per_cell": None, "source": None}
+    sd = (pmc or {}).get("seed")
+    if sd and sd.get("cells") == seed_cells and sd.get("profiled_kernel_ms") and abs(sd["profiled_kernel_ms"] - seed_ms) <= PMC_MAX_DRIFT * seed_ms:
+        out["executed_slots_per_cell"] = round(sd["insts_valu"] * 64.0 / seed_cells, 3)
+        out["valu_issue_utilisation"] = round(sd["insts_valu"] * float(ISSUE_CYCLES) / (info["compute_units"] * 4 * sd["gui_active"] / 8.0), 4)
         out["source"] = pmc["source"]
     return out
 
@@ -170,7 +224,18 @@ def main():
                     help="engine slots the timed steps alternate over (steps in flight at once: the fetch of step k is taken after "
                          "step k+S-1 has been launched).  1: every step is launched, waited for and fetched before the next")
     ap.add_argument("--only-variants", action="store_true", help="of what a default N=1 run appends, the variants alone (profiling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): one genome block of --workload per rank, per-GPU work fixed; strong: the FIXED job "
+                         "`--workload config4` (eight pacbio50mb genome blocks, 40,000 reads, 2.67 M candidates) dealt over the N ranks")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config4_strong entry every default line carries")
+    ap.add_argument("--no-reference-caller", action="store_true",
+                    help="skip the reference's own unmodified darwin.cpp on the engine (a child process behind the timed region, N = 1)")
+    ap.add_argument("--no-cabi-gather-check", action="store_true", help="N > 1: skip the second gather through the C-ABI's own RCCL path")
     args = ap.parse_args()
+    if args.workload == "config4":
+        args.scaling = "strong"
+    if args.scaling == "strong" and args.workload not in ("config4", "ecoli10x"):
+        raise SystemExit("bench.py: --scaling strong runs the fixed job `--workload config4`")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -196,6 +261,17 @@ def main():
     import numpy as np
     from gact_amd import engine, workload
     from gact_amd import dist as gdist
+
+    if args.scaling == "strong":
+        # the fixed job of BASELINE config 4 as the headline: same line, "scaling": "strong"
+        entry = config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps=args.steps, warmup=args.warmup, headline=True)
+        if rank == 0:
+            print(json.dumps(entry))
+            sys.stdout.flush()
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- workload: one genome block per rank, read sets replicated everywhere
     t_gen = time.time()
@@ -315,7 +391,8 @@ def main():
             raise SystemExit("bench.py: %s" % err)
         # the same gather once more through the C-ABI's own RCCL path (gact_hip_comm_*, what host/darwin_hip --rccl-gather
         # uses), outside the timed region, compared on rank 0 with what torch.distributed delivered
-        cpp_gather = cpp_gather_check(eng, dist, rank, world, nf + nr, gathered)
+        cpp_gather = {"ok": None, "skipped": "--no-cabi-gather-check"} if args.no_cabi_gather_check else \
+            cpp_gather_check(eng, dist, torch, rank, world, nf + nr, gathered)
     for k in sorted(ran - {0}):    # every slot that took a step holds the same records
         if eng.candidates_fetch(nf + nr, slot=k).tobytes() != eng.candidates_fetch(nf + nr, slot=0).tobytes():
             raise SystemExit("bench.py: slot %d's records differ from slot 0's" % k)
@@ -354,16 +431,28 @@ def main():
         # issue peak: one wave64 VALU instruction per SIMD per 2 cycles = 128 lane-op slots per CU per clock
         peak_slots = info["compute_units"] * NOMINAL_LANES_PER_CU_CLK * info["clock_mhz"] * 1e6 / 1e12
         linear = bool(kernel_ms[-1].get("linear_gap"))
-        floor, model = floor_slots_per_cell(linear, eng.tile_size, eng.tile_size - eng.tile_overlap)
+        floor, model = floor_slots_per_cell(linear, eng.tile_size, eng.tile_size - eng.tile_overlap,
+                                            affine_drift=bool(kernel_ms[-1].get("affine_drift")))
         achieved = floor * main_cells / (k_ms * 1e-3) / 1e12
         pmc = pmc_lookup(args.workload, args.candidates, main_kernel, main_cells)
         executed = traffic = traffic_source = None
+        pmc_refused = None
+        if pmc and not pmc_within_drift(pmc, k_ms):
+            # the committed counters were taken at another kernel time (another build, another box): not quoted as this run's
+            pmc_refused = "%s refused: taken at %.2f ms, this run %.2f ms (more than %d %% apart)" % (
+                pmc["source"], pmc["profiled_kernel_ms"] or 0.0, k_ms, int(PMC_MAX_DRIFT * 100))
+            pmc_seed, pmc = pmc, None
+        else:
+            pmc_seed = pmc
         if pmc:
             slots = pmc["insts_valu"] * 64.0 / main_cells
             # GRBM_GUI_ACTIVE counts over the 8 XCDs; 1024 SIMDs, 2 cycles per issue at the peak
             util = pmc["insts_valu"] * float(ISSUE_CYCLES) / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0)
             executed = {"slots_per_cell": round(slots, 3), "valu_issue_utilisation": round(util, 4),
                         "floor_over_executed": round(floor / slots, 4), "profiled_kernel_ms": pmc["profiled_kernel_ms"],
+                        # counters cannot be read from inside this process: they are the committed rocprofv3 --pmc pass of this
+                        # command; how far this run's kernel time is from the one they were taken at
+                        "kernel_ms_drift": round(k_ms / pmc["profiled_kernel_ms"] - 1.0, 4) if pmc["profiled_kernel_ms"] else None,
                         "source": pmc["source"] + " (SQ_INSTS_VALU, GRBM_GUI_ACTIVE of this kernel on this workload; "
                                   "utilisation = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))"}
             # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16-byte) streaming reads by 2x -- the walker's
@@ -393,7 +482,7 @@ def main():
             "unit": "T lane-op slots/s (one lane of one wave64 VALU instruction; int16 pairs: two DP cells per slot)",
             "frac": round(achieved / peak_slots, 4),
             "model": dict(model, slots_per_cell=round(floor, 3), scoring="linear gaps" if linear else "affine gaps"),
-            "executed": executed,
+            "executed": executed, "pmc_refused": pmc_refused,
             "traffic": traffic, "traffic_source": traffic_source,
             "kernel": main_kernel,
             "measured_in": "%d steps run one at a time in the plain sequence right after the timed region (see `mode`); "
@@ -410,6 +499,8 @@ def main():
                                   "peak_gcups_at_24_ops": round(peak_slots * 1e3 / OPS_PER_CELL, 1)},
             "compute_units": info["compute_units"], "clock_mhz": info["clock_mhz"],
             "waves_per_cu": info["waves_per_cu"],
+            # the seed launch against the same peak (every kernel that is 5 % of a step or more has a frac in this line)
+            "seed": seed_roofline(kernel_ms[-1], seed_ms, seed_cells, info, pmc_seed),
         }
         # ---- the same roofline for what `value` measured: every kernel of a step (seed, main, ordering, gather) against
         #      the wall time of a step with S steps in flight.  Algorithmic slots: the floor above over ALL cells of a step
@@ -479,10 +570,27 @@ def main():
                 out["feeder_threads"] = feeder_config(args.workload, cat, offs, rcat, my_cf, my_cr, rec)
                 out["other_configs"] = [side_config(w, args) for w in ("pacbio50mb", "ont")]
             out["variants"] = [variant_config(v, args.workload, reads, my_cf, my_cr) for v in VARIANTS]
+    # ---- the fixed eight-block job of BASELINE config 4 dealt over these N ranks (strong scaling): every default line carries it
+    if not args.no_config4 and not args.only_variants and not _CPP_GATHER_STUCK and args.workload == "ecoli10x":
+        if eng is not None:
+            eng.close()
+            eng = None
+        entry = config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps=3, warmup=1, headline=False)
+        if rank == 0:
+            out["config4_strong"] = entry
+    if rank == 0:
+        if world == 1 and not use_dist and not args.no_reference_caller and args.workload == "ecoli10x" and not args.only_variants:
+            if eng is not None:
+                eng.close()
+                eng = None
+            out["reference_caller"] = reference_caller()
         print(json.dumps(out))
         sys.stdout.flush()
     if use_dist and _CPP_GATHER_STUCK:
-        os._exit(0)            # a collective of the C-ABI check never came back on this rank: its thread cannot be joined
+        # a collective of the C-ABI check never came back on SOME rank (every rank knows: the flag was all-reduced): the
+        # check's thread cannot be joined and the communicator is not to be trusted -- the line is out, every rank leaves
+        # the same way, and not with a success code
+        os._exit(3)
     if eng is not None:
         eng.close()
     if use_dist:
@@ -493,10 +601,211 @@ def main():
 _CPP_GATHER_STUCK = False
 
 
-def cpp_gather_check(eng, dist, rank, world, n, gathered):
+def _config4_build_one(b):
+    from gact_amd import workload
+    return workload.config4_blocks([b])[0]
+
+
+def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, warmup, headline):
+    """BASELINE config 4 as ONE node runs it, and as a strong-scaling job: the FIXED set of eight pacbio50mb genome blocks
+    (40,000 reads of ~10 kb, 418 Mb, three resident sets on every GPU; 2.67 M D-SOFT candidates, 8.2e12 cells per step),
+    the merged candidate list dealt round-robin over the N ranks, one gather of 32-byte lines to rank 0.
+    Steps, barriers and the max-over-ranks clock as in the headline.  The reference has nothing to mirror
+    (cuda_host.cu:195 hard-wires device 0); the join is README:25's `cat | sort`.
+    Parity inside the run: the ranks that hold rank 0's / rank 5's share OF EIGHT compare every one of those records
+    with the oracle's golden records (tests/golden/config_config4_rank{0,5}.npz)."""
+    import zlib
+    import numpy as np
+    from gact_amd import engine, workload, synth
+    from gact_amd import dist as gdist
+    NB = workload.CONFIG4_BLOCKS
+    t0 = time.time()
+    mine = list(range(rank, NB, world))
+    if world == 1 and not use_dist:
+        # one process builds all eight: four at a time (each filter holds a 1 GiB index and a quarter of the cores)
+        # (fresh interpreters: this process has a HIP runtime in it by now)
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+        saved = os.environ.get("LOCAL_WORLD_SIZE")
+        os.environ["LOCAL_WORLD_SIZE"] = "4"
+        try:
+            with ProcessPoolExecutor(4, mp_context=multiprocessing.get_context("spawn")) as pool:
+                built = dict(pool.map(_config4_build_one, mine))
+        finally:
+            if saved is None:
+                os.environ.pop("LOCAL_WORLD_SIZE", None)
+            else:
+                os.environ["LOCAL_WORLD_SIZE"] = saved
+    else:
+        built = dict(workload.config4_blocks(mine, candidates=args.candidates))
+    blocks = gdist.exchange_block_rounds(dist, built, NB, rank, world, torch=torch, device="cuda" if use_dist else "cpu")
+    reads, cf_all, cr_all = gdist.merge_blocks(blocks)
+    offs = np.zeros(len(reads) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    cat = np.concatenate(reads)
+    rcat = np.concatenate([synth.revcomp(r) for r in reads])
+    my_cf, my_cr = gdist.deal(cf_all, rank, world), gdist.deal(cr_all, rank, world)
+    nf, nr = len(my_cf), len(my_cr)
+    t_build = time.time() - t0
+
+    S = max(1, args.slots)
+    eng = engine.Engine(device_id=local_rank, n_slots=S)
+    info = eng.device_info()
+    eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, offs)
+    cands = np.concatenate([my_cf, my_cr])
+    bufs = [np.zeros(nf + nr, dtype=engine.OVERLAP_DTYPE) for _ in range(S)]
+    for k in range(S):
+        eng.candidates_upload(cands, slot=k)
+        eng.register_output(bufs[k], slot=k)
+    gather = dev_recs = None
+    if use_dist:
+        gather = gdist.RecordGather(torch, dist, nf + nr, gdist.LINE_BYTES, rank, world, "cuda")
+        dev_recs = [gdist.DeviceRecords(eng.device_overlaps_ptr(k), nf + nr, engine.OVERLAP_DTYPE.itemsize) for k in range(S)]
+    gather_s = [0.0]
+
+    def barrier():
+        for k in range(S):
+            eng.sync(k)
+        if use_dist:
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+
+    def launch(slot):
+        eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=slot)
+
+    def complete(slot):
+        if use_dist:
+            eng.sync(slot)
+            tg = time.perf_counter()
+            parts = gather(dev_recs[slot])
+            out = gather.to_host(parts, gdist.LINE_DTYPE) if rank == 0 else None
+            gather_s[0] += time.perf_counter() - tg
+            return None, out
+        return eng.candidates_fetch(nf + nr, slot=slot, out=bufs[slot]), None
+
+    eng.set_option("runs_in_flight", 1 if S > 1 else 0)
+    gdist.run_pipelined(warmup, S, launch, complete)
+    barrier()
+    gather_s[0] = 0.0
+    t1 = time.perf_counter()
+    rec, gathered = gdist.run_pipelined(steps, S, launch, complete) or (None, None)
+    eng.sync(0)
+    my_dt = time.perf_counter() - t1                                # this rank's own steps (its last gather included)
+    barrier()
+    dt = time.perf_counter() - t1
+    eng.set_option("runs_in_flight", 0)
+    # one run at a time on this rank (what a caller that submits its list once sees), outside the timed region
+    t2 = time.perf_counter()
+    launch(0)
+    single_rec = eng.candidates_fetch(nf + nr, slot=0, out=bufs[0]).copy()
+    dt_single = time.perf_counter() - t2
+    st = eng.last_run_stats(0)
+    rec = single_rec
+    my_cells, my_tiles = int(rec["cells"].sum()), int(rec["n_tiles"].sum())
+    # ---- parity: rank g of EIGHT's share is the golden file's; here it lies on rank g % world, every (8 / world)-th record
+    checked = {}
+    for g in (0, 5):
+        path = os.path.join(ROOT, "tests", "golden", "config_config4_rank%d.npz" % g)
+        if NB % world or g % world != rank or not os.path.exists(path):
+            continue
+        gold = np.load(path)
+        stride, first = NB // world, g // world
+        got = np.concatenate([rec[:nf][first::stride], rec[nf:][first::stride]])
+        sub = np.concatenate([my_cf[first::stride], my_cr[first::stride]])
+        if int(gold["candidates_crc"]) != zlib.crc32(sub.tobytes()):
+            raise SystemExit("bench.py: tests/golden/config_config4_rank%d.npz was made for another candidate list" % g)
+        bad = np.flatnonzero(workload.record_crcs(got) != gold["crc"])
+        if len(bad):
+            raise SystemExit("bench.py: PARITY FAILURE, config 4: %d records of rank %d of 8 differ from the oracle's golden records, first %s"
+                             % (len(bad), g, got[bad[0]]))
+        checked["rank%d_of_8" % g] = int(len(got))
+    tot_cells, tot_tiles, max_dt = my_cells, my_tiles, dt
+    per_rank_ms, per_rank_single, gather_ms, all_checked, builds = [my_dt / steps * 1e3], [dt_single * 1e3], None, dict(checked), [round(t_build, 1)]
+    if use_dist:
+        v = torch.tensor([float(my_cells), float(my_tiles)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v)
+        tot_cells, tot_tiles = int(v[0].item()), int(v[1].item())
+        m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        max_dt = float(m.item())
+        row = torch.tensor([my_dt / steps * 1e3, dt_single * 1e3, float(sum(checked.values())), t_build, gather_s[0] / steps * 1e3],
+                           dtype=torch.float64, device="cuda")
+        rows = [torch.zeros_like(row) for _ in range(world)]
+        dist.all_gather(rows, row)
+        rows = [[float(x) for x in r.tolist()] for r in rows]
+        per_rank_ms = [r[0] for r in rows]; per_rank_single = [r[1] for r in rows]; builds = [round(r[3], 1) for r in rows]
+        all_checked = {"records_checked_against_golden_all_ranks": int(sum(r[2] for r in rows))}
+        gather_ms = round(rows[0][4], 3)
+        # what rank 0 gathered of every rank is what that rank's engine holds
+        try:
+            gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
+        except RuntimeError as err:
+            raise SystemExit("bench.py: config 4: %s" % err)
+    eng.close()
+    if rank != 0:
+        return None
+    gcups = tot_cells * steps / max_dt / 1e9
+    entry = {
+        "workload": "config4_fixed_job (8 pacbio50mb genome blocks, self-overlap)", "scaling": "strong",
+        "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(max_dt / steps * 1e3, 3), "slots_in_flight": S,
+        "reads": len(reads), "bases": int(offs[-1]), "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles, "cells_per_step": tot_cells,
+        "parallelism": "the merged candidate list dealt round-robin over %d GPU(s), read sets replicated" % world,
+        # every rank's own time per step (its steps launched, waited for, its part of the gather done) and the one gather as
+        # rank 0 sees it (the wait for the slowest rank included)
+        "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3), "all": [round(x, 3) for x in per_rank_ms]},
+        "gather_ms_per_step_rank0": gather_ms,
+        "single_run_ms_per_rank": {"min": round(min(per_rank_single), 2), "max": round(max(per_rank_single), 2)},
+        "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else "") + ("-roles" if st.get("role_waves") else ""),
+        "kernel_ms": round(st["main_ms"], 3), "seed_kernel_ms": round(st["seed_ms"], 3),
+        "parity": dict(all_checked, bit_exact=True, golden="tests/golden/config_config4_rank{0,5}.npz (every record of two ranks of eight, from the oracle)"),
+        "build_seconds_per_rank": builds,
+        "note": "no scaling curve is claimed from this entry at one N: the driver's 1/2/4/8 runs each carry it" if not headline else None,
+    }
+    if not headline:
+        return entry
+    # the contract's line for `--scaling strong --workload config4`
+    return {"metric": "GACT GCUPS (DP cells/s) on ~10 kb PacBio-shape reads", "value": entry["value"], "unit": "GCUPS", "n_gpus": world,
+            "steps": steps, "warmup": warmup, "ms_per_step": entry["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "int16x2 (packed)", "data": "synthetic",
+            "config": {"workload": "config4_fixed_job", "tile_size": 320, "tile_overlap": 120, "scoring": "+1/-1/-1/-1",
+                       "reads": entry["reads"], "bases": entry["bases"], "candidates": entry["candidates"], "cells_per_step": tot_cells,
+                       "parallelism": entry["parallelism"], "slots_in_flight": S, "arch": info["arch"]},
+            "config4_strong": entry}
+
+
+def reference_caller(threads=8):
+    """The reference's own UNMODIFIED darwin.cpp (-DGPU, oracle/_ref/darwin_on_hip: built on host/gact.h + gact_shim.cpp) on the
+    headline workload's FASTA with eight feeder threads, as a child process behind the timed region: what its threads print
+    as "Time GACT calling" (darwin.cpp:408-441: both GACT_Batch calls of a thread), as it is and with GACT_HIP_PAIR_STRANDS=1,
+    its lines compared with this repo's own pipeline's (tools/darwin_on_hip_timing.py)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "darwin_on_hip")
+    if not os.path.exists(exe):
+        return {"time_gact_calling_ms": None, "note": "oracle/_ref/darwin_on_hip not present on this box (built from /root/reference where that is mounted)"}
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "darwin_on_hip_timing.py"), "ecoli10x", str(threads), "1"],
+                           capture_output=True, text=True, timeout=420)
+        if p.returncode != 0:
+            return {"time_gact_calling_ms": None, "error": (p.stdout + p.stderr)[-400:]}
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        runs = d["runs"]
+        return {"caller": "the reference's darwin.cpp -DGPU, unmodified, on host/gact.h + gact_shim.cpp (oracle/_ref/darwin_on_hip)",
+                "feeder_threads": d["feeder_threads"], "reads": d["reads"], "candidates": d["candidates"], "cells": d["cells"],
+                "time_gact_calling_ms": runs[0]["gact_calling_ms_max_over_threads"], "gcups": runs[0]["gcups_of_the_gact_stage"],
+                "launch_ms_on_the_device": sorted(set(c["launch_ms"] for c in runs[0]["shim_split_per_call_us"])),
+                "callers_merged": sorted(set(c["merged"] for c in runs[0]["shim_split_per_call_us"])),
+                "paired_ms": runs[1]["gact_calling_ms_max_over_threads"] if len(runs) > 1 else None,
+                "lines": d["lines"], "lines_equal": bool(d["lines_equal_between_modes_and_to_this_repos_own_pipeline"])}
+    except Exception as err:                                    # (reported, never fatal for the line)
+        return {"time_gact_calling_ms": None, "error": str(err)[:300]}
+
+
+def cpp_gather_check(eng, dist, torch, rank, world, n, gathered):
     """One gather of slot 0's records over the C-ABI's RCCL path (include/gact_hip.h gact_hip_comm_create / _gather_lines),
     every rank; rank 0 compares the lines with what the torch.distributed gather of the step delivered.  Run on a thread
-    with a time limit: the check must never keep the bench line from being printed."""
+    with a time limit: the check must never keep the bench line from being printed.  Whether ANY rank got stuck is
+    all-reduced over torch's own communicator, so that every rank takes the same way out (one rank leaving
+    through os._exit while the others walk into the final barrier)."""
     global _CPP_GATHER_STUCK
     import tempfile
     import threading
@@ -524,10 +833,12 @@ def cpp_gather_check(eng, dist, rank, world, n, gathered):
 
     th = threading.Thread(target=work, daemon=True)
     th.start()
-    th.join(120)
-    if th.is_alive():
+    th.join(60)
+    stuck = torch.tensor([1.0 if th.is_alive() else 0.0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(stuck, op=dist.ReduceOp.MAX)
+    if float(stuck.item()) > 0:
         _CPP_GATHER_STUCK = True
-        return {"ok": False, "error": "no answer within 120 s"}
+        return {"ok": False, "error": "no answer within 60 s on %s" % ("this rank" if th.is_alive() else "another rank")}
     if "error" in res:
         return {"ok": False, "error": res["error"]}
     out = {"ok": True, "records_per_rank": res["counts"], "create_ms": res["create_ms"], "first_gather_ms": res["first_gather_ms"],
@@ -709,8 +1020,8 @@ def variant_config(v, workload_name, reads, cf, cr):
     saved = {k: os.environ.get(k) for k in v.get("env", {})}
     os.environ.update(v.get("env", {}))
     try:
-        return timed_config({"workload": workload_name + "_self_overlap", "variant": v["label"]}, cat, offs, rcat, offs, cf, cr,
-                            scoring=v.get("scoring", (1, -1, -1, -1)))
+        return timed_config({"workload": workload_name + "_self_overlap", "variant": v["label"], "variant_index": VARIANTS.index(v)},
+                            cat, offs, rcat, offs, cf, cr, scoring=v.get("scoring", (1, -1, -1, -1)))
     finally:
         for k, old in saved.items():
             if old is None:
@@ -797,10 +1108,12 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
                 "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
                 "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
                 "parity": {"checked_candidates": int(checked), "bit_exact": True}})
-    if st["packed16"] and head.get("variant") is None:
+    if st["packed16"]:
         # the main launch of the one-at-a-time leg against the issue peak (counters: the committed PMC pass of this workload)
+        wl = head["workload"].replace("_self_overlap", "") + ("" if head.get("variant") is None else "_variant_%d" % head.get("variant_index", 0))
         out["roofline"] = short_roofline(st, float(np.mean([x["main_ms"] for x in stats])), cells - int(st["seed_cells"]), info,
-                                         head["workload"].replace("_self_overlap", ""), eng_tile, eng_tile - eng_overlap)
+                                         wl, eng_tile, eng_tile - eng_overlap)
+        out["roofline"]["seed"] = seed_roofline(st, float(np.mean([x["seed_ms"] for x in stats])), int(st["seed_cells"]), info, None) if st["seed_cells"] else None
     return out
 
 

@@ -1264,8 +1264,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     if (p->max_blocks > 0) {                // a small engine (gact_hip_params.max_blocks): every persistent grid capped, the workspace with them
         for (int *g : {&e->grid_blocks, &e->seed_grid_blocks, &e->seed_lin_grid_blocks, &e->lin_grid_blocks, &e->wide_lin_grid_blocks, &e->aff_grid_blocks})
             *g = std::max(1, std::min(*g, (int)p->max_blocks));
-        // (a role block is six waves where the others are four)
-        if (e->roles) e->role_grid_blocks = std::max(1, std::min(e->role_grid_blocks, (int)p->max_blocks * 4 / (gact::kRoleDp + 1)));
+        // (a role block is twelve waves where the others are four)
+        if (e->roles) e->role_grid_blocks = std::max(1, std::min(e->role_grid_blocks, (int)p->max_blocks * 4 / (gact::kRoleDp + gact::kRoleWalk)));
     }
     e->ws_words_total = ws_words_for(std::max(std::max(e->grid_blocks, e->aff_grid_blocks), std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
     if (e->roles) {

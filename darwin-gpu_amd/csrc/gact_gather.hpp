@@ -223,7 +223,11 @@ int gact_hip_comm_gather_lines(gact_hip_comm *c, int slot, int32_t n, int64_t *c
         HIP_TRY(hipStreamSynchronize(c->stream));
         return 0;
     }
-    if (!lines || lines_cap < total) return fail(GACT_HIP_EINVAL, "comm_gather_lines: rank 0 needs room for %lld lines (got %lld)", total, (long long)(lines ? lines_cap : 0));
+    // (rank 0's caller may have brought too small an array, or none: the other ranks are in their sends by now and know
+    //  nothing of it, so the receives are posted and waited for all the same -- into the communicator's own device array,
+    //  sized from the counts -- and the error is reported once the collective is over.  `counts` holds what is needed:
+    //  a call with lines == NULL is the way to ask.)
+    const bool room = lines && lines_cap >= total;
     if ((size_t)total > c->all_cap) {
         if (c->d_all) (void)hipFree(c->d_all);
         c->d_all = nullptr; c->all_cap = 0;
@@ -243,7 +247,8 @@ int gact_hip_comm_gather_lines(gact_hip_comm *c, int slot, int32_t n, int64_t *c
         at += cnt;
     }
     RCCL_TRY(g_rccl.GroupEnd());
-    if (total > 0) HIP_TRY(hipMemcpyAsync(lines, c->d_all, (size_t)total * sizeof(gact_line), hipMemcpyDeviceToHost, c->stream));
+    if (room && total > 0) HIP_TRY(hipMemcpyAsync(lines, c->d_all, (size_t)total * sizeof(gact_line), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!room) return fail(GACT_HIP_EINVAL, "comm_gather_lines: rank 0 needs room for %lld lines (got %lld); the gather itself was completed", total, (long long)(lines ? lines_cap : 0));
     return 0;
 }

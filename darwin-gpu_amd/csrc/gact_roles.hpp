@@ -6,13 +6,12 @@
 // during which it issues next to nothing, and the SIMD's other waves cannot make up for it.  Candidates are
 // independent (gact.cpp:48); only tile k+1 of the SAME candidate needs tile k's walk (gact.cpp:82-134).  So here
 //
-//   * a block is kRoleDp DP waves and ONE walker wave;
+//   * a block is kRoleDp DP waves and kRoleWalk walker waves (10 + 2: one block per CU, three waves per SIMD);
 //   * a DP wave carries TWO banks of eight tiles (2 x 4 groups x {A, B}).  It runs bank 0's pass, posts the eight walks as
 //     jobs in LDS, runs bank 1's pass while the walker wave walks bank 0, comes back to bank 0, finds the results, advances
 //     its chains (gact.cpp:111-133), picks and loads their next tiles, and so on: a DP wave is inside a pass all the time;
-//   * lane n of the walker wave serves tile slot n of its block (DP wave n / 8, group (n % 8) / 2, slot n % 2): up to
-//     8 * kRoleDp walks side by side in one instruction stream instead of 8 -- the walk's instructions per tile drop
-//     by the same factor.  Its region refills (tb_refill_oct: eight 16-byte loads past the L1, one round trip) are taken
+//   * lane n of a walker wave serves one tile slot of its block (DP wave / group / slot): up to 40 walks side by side in
+//     one instruction stream instead of 8 -- the walk's instructions per tile drop by the same factor.  Its region refills (tb_refill_oct: eight 16-byte loads past the L1, one round trip) are taken
 //     by all walking lanes at the same trip, once per eight moves, exactly the cadence of walk_chain_lin.
 //
 // The walk itself is walk_chain_lin's, move for move (same cells, same order, same stop tests, same band rule): the two
@@ -31,15 +30,19 @@
 
 namespace gact {
 
+// A block is ONE PER CU: 10 DP waves + 2 walker waves = three waves on every SIMD.  (Blocks of 5 + 1 waves, two per CU, were
+// what the occupancy calculator allowed and what round 5 tried first: only one of them became resident per CU -- six waves of
+// 168 registers do not spread 2-2-1-1 over the SIMDs twice -- and the launch ran on half its DP waves.)
 #ifndef GACT_ROLE_DP_WAVES
-#define GACT_ROLE_DP_WAVES 5
+#define GACT_ROLE_DP_WAVES 10
 #endif
-constexpr int kRoleDp = GACT_ROLE_DP_WAVES;                 // DP waves per block; + 1 walker wave
-constexpr int kRoleThreads = 64 * (kRoleDp + 1);
-constexpr int kRoleBlocksPerCu = 12 / (kRoleDp + 1);        // three waves per SIMD, as the pass is written for
+constexpr int kRoleDp = GACT_ROLE_DP_WAVES;                 // DP waves per block
+constexpr int kRoleWalk = kRoleDp > 7 ? 2 : 1;              // walker waves per block
+constexpr int kRoleThreads = 64 * (kRoleDp + kRoleWalk);
 constexpr int kRoleBanks = 2;
-constexpr int kRoleJobs = kRoleDp * 8;                      // tile slots of a block = walker lanes at work
-static_assert(kRoleJobs <= 64, "one walker wave per block");
+constexpr int kRoleJobs = kRoleDp * 8;                      // tile slots of a block
+constexpr int kRoleJobsPerWalker = kRoleJobs / kRoleWalk;   // ... and of a walker wave: its lanes at work
+static_assert(kRoleDp % kRoleWalk == 0 && kRoleJobsPerWalker <= 64, "a walker wave serves whole DP waves, a lane per tile slot");
 constexpr int kRoleCacheStride = 36;                        // dwords of region cache per walker lane (32 used; 36: eight banks apart)
 
 struct WalkJob {                 // DP wave -> walker lane
@@ -77,8 +80,10 @@ __device__ __forceinline__ void role_walker(const KParams &kp, const uint32_t *_
     typedef __attribute__((address_space(3))) const uint8_t LdsByte;
     typedef __attribute__((address_space(3))) const uint32_t LdsWord;
     typedef __attribute__((address_space(3))) volatile uint32_t LdsFlag;
-    const int lane = threadIdx.x & 63;
-    const bool serving = lane < kRoleJobs;
+    const int wlane = threadIdx.x & 63;
+    const bool serving = wlane < kRoleJobsPerWalker;
+    // (the tile slot this lane serves; idle lanes look at the wave's first slot and never act)
+    const int lane = ((threadIdx.x >> 6) - kRoleDp) * kRoleJobsPerWalker + (serving ? wlane : 0);
     uint32_t *scratch = cache_all + lane * kRoleCacheStride;
     LdsByte *cache = (LdsByte *)scratch;
     LdsWord *stage = (LdsWord *)stage_all;

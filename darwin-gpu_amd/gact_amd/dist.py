@@ -93,6 +93,22 @@ def exchange_blocks(dist, block, world, torch=None, device="cpu"):
     return [_unpack_block(o.cpu().numpy(), sz, cand_dtype) for o, sz in zip(outs, all_sizes)]
 
 
+def exchange_block_rounds(dist, built, n_blocks, rank, world, torch=None, device="cpu"):
+    """A FIXED job of n_blocks genome blocks over `world` ranks (strong scaling): rank r built the blocks b with b % world == r
+    (`built`: {b: (reads, cands_fwd, cands_rc)}); afterwards every rank holds all n_blocks, in block order.  One
+    exchange_blocks round per ceil(n_blocks / world): block k * world + r travels in round k from rank r, a rank with no block
+    left sends an empty one."""
+    from . import synth
+    empty = ([], np.zeros(0, dtype=synth.CAND_DTYPE), np.zeros(0, dtype=synth.CAND_DTYPE))
+    blocks = [None] * n_blocks
+    for k in range((n_blocks + world - 1) // world):
+        got = exchange_blocks(dist, built.get(k * world + rank, empty), world, torch=torch, device=device)
+        for r, g in enumerate(got):
+            if k * world + r < n_blocks:
+                blocks[k * world + r] = g
+    return blocks
+
+
 class DeviceRecords:
     """The engine's device-resident overlap records (gact_hip_device_overlaps) as something torch can wrap without a
     copy: the CUDA array interface, which torch.as_tensor honours on ROCm as well."""

@@ -14,7 +14,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
            ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp", "gact_lin.hpp",
-            "gact_aff.hpp", "gact_big.hpp", "gact_gather.hpp", "dsoft_device.hpp", "dsoft_engine.hpp")] + \
+            "gact_aff.hpp", "gact_roles.hpp", "gact_big.hpp", "gact_gather.hpp", "dsoft_device.hpp", "dsoft_engine.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
 SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2

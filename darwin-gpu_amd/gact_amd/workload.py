@@ -98,3 +98,27 @@ def make_block(name, block=0, candidates="dsoft"):
 def shard(cands, rank, world):
     """round-robin deal of a candidate list"""
     return np.ascontiguousarray(cands[rank::world])
+
+
+# ---- golden records (tests/golden/config_*.npz, made by tests/golden/make_config_golden.py from the oracle): one CRC-32 per
+#      record over the twelve fields the parity tests compare
+RECORD_FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
+
+
+def record_crcs(rec):
+    """one CRC-32 per record over RECORD_FIELDS as int64"""
+    import zlib
+    a = np.ascontiguousarray(np.stack([rec[f].astype(np.int64) for f in RECORD_FIELDS], axis=1))
+    return np.fromiter((zlib.crc32(row.tobytes()) for row in a), dtype=np.uint32, count=len(a))
+
+
+CONFIG4_BLOCKS = 8        # BASELINE config 4 in the form one node runs it: eight pacbio50mb genome blocks, 40,000 reads, 418 Mb
+
+
+def config4_blocks(mine, candidates="dsoft"):
+    """the genome blocks `mine` (indices) of the config-4 job: [(index, (reads, cands_fwd, cands_rc))]"""
+    out = []
+    for b in mine:
+        blk = make_block("pacbio50mb", block=b, candidates=candidates)
+        out.append((b, (blk.rs.reads, blk.cf, blk.cr)))
+    return out

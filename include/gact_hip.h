@@ -335,7 +335,9 @@ int gact_hip_comm_create(gact_hip_engine *e, int32_t rank, int32_t world, const 
                          gact_hip_comm **out);
 /* Collective.  The first n records of `slot` (its last run's; the call waits for that run on the device) travel to rank 0.
  * counts[world] (every rank, may be NULL): records per rank.  lines (rank 0): all of them, rank after rank, each rank's in
- * candidate order; lines_cap = room in `lines`, in records.  Other ranks pass NULL, 0. */
+ * candidate order; lines_cap = room in `lines`, in records.  Other ranks pass NULL, 0.
+ * Too little room on rank 0 (or lines == NULL) does not break the collective: the records are received all the same, the other
+ * ranks return 0, rank 0 returns GACT_HIP_EINVAL with counts[] filled in -- call again with room for their sum. */
 int gact_hip_comm_gather_lines(gact_hip_comm *c, int slot, int32_t n, int64_t *counts, gact_line *lines, int64_t lines_cap);
 int gact_hip_comm_destroy(gact_hip_comm *c);
 

@@ -22,14 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 for p in (os.path.join(ROOT, "darwin-gpu_amd"), os.path.join(ROOT, "oracle")):
     sys.path.insert(0, p)
 
-FIELDS = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted", "first_tile_score", "n_tiles", "cells")
-
-
-def record_crcs(rec):
-    """one CRC-32 per record over FIELDS as int64"""
-    a = np.stack([rec[f].astype(np.int64) for f in FIELDS], axis=1)
-    a = np.ascontiguousarray(a)
-    return np.fromiter((zlib.crc32(row.tobytes()) for row in a), dtype=np.uint32, count=len(a))
+from gact_amd.workload import RECORD_FIELDS as FIELDS, record_crcs        # (shared with bench.py's config-4 parity gate)
 
 
 def _config4_block(b):

@@ -72,6 +72,60 @@ def test_two_ranks_gather_equals_single_process(world):
     assert sum(sizes) == nf + nr and max(sizes) - min(sizes) <= 2
 
 
+def _strong_worker(rank, world, port, q):
+    """bench.py's strong-scaling job (config4_strong): a FIXED set of blocks, rank r builds the blocks b % world == r, the
+    rounds of exchange_block_rounds put all of them on every rank, the merged list is dealt over the ranks"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "darwin-gpu_amd"))
+    import zlib
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gact_amd import dist as gdist, workload
+    NB = 5
+    built = {}
+    for b in range(rank, NB, world):
+        blk = workload.make_block("tiny", block=b, candidates="synthetic")
+        built[b] = (blk.rs.reads, blk.cf, blk.cr)
+    blocks = gdist.exchange_block_rounds(dist, built, NB, rank, world)
+    reads, cf_all, cr_all = gdist.merge_blocks(blocks)
+    q.put((rank, len(reads), zlib.crc32(np.concatenate(reads).tobytes()), zlib.crc32(cf_all.tobytes()), zlib.crc32(cr_all.tobytes()),
+           len(gdist.deal(cf_all, rank, world)) + len(gdist.deal(cr_all, rank, world))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_fixed_job_of_blocks_over_ranks(world):
+    """every rank ends up with the job a single process builds, whatever the number of ranks (strong scaling)"""
+    import zlib
+    import torch.multiprocessing as mp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "darwin-gpu_amd"))
+    from gact_amd import dist as gdist, workload
+    single = []
+    for b in range(5):
+        blk = workload.make_block("tiny", block=b, candidates="synthetic")
+        single.append((blk.rs.reads, blk.cf, blk.cr))
+    reads, cf_all, cr_all = gdist.merge_blocks(gdist.exchange_block_rounds(None, dict(enumerate(single)), 5, 0, 1))
+    want = (len(reads), zlib.crc32(np.concatenate(reads).tobytes()), zlib.crc32(cf_all.tobytes()), zlib.crc32(cr_all.tobytes()))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    rows = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in rows) == list(range(world))
+    assert all(tuple(r[1:5]) == want for r in rows), (rows, want)
+    assert sum(r[5] for r in rows) == len(cf_all) + len(cr_all)
+
+
 def _pipeline_worker(rank, world, port, q):
     """bench.py's timed region at N > 1 with steps in flight, the engine stood in for by tagged records: every rank
     launches step k on slot k % S and completes (= gathers) the steps in launch order; rank 0 must receive, at its k-th

@@ -3,7 +3,7 @@ against host/gact.h + gact_shim.cpp, tests/test_reference_caller.py) on a worklo
 its threads print as "Time GACT calling" (darwin.cpp:424-441: both GACT_Batch calls of a thread) against the DP cells of
 the workload.  Once as it is -- forward call, then reverse-complement call, each merged across the threads by the engine's
 call combiner -- and once with GACT_HIP_PAIR_STRANDS=1 (the shim runs a thread's two calls as one).  Lines compared.
-python tools/darwin_on_hip_timing.py [workload] [threads]"""
+python tools/darwin_on_hip_timing.py [workload] [threads] [repetitions per mode, default 2]"""
 import json
 import os
 import re
@@ -19,6 +19,7 @@ from gact_amd import engine, workload
 
 name = sys.argv[1] if len(sys.argv) > 1 else "ecoli10x"
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 exe = os.path.join(ROOT, "oracle", "_ref", "darwin_on_hip")
 if not os.path.exists(exe):
     raise SystemExit("oracle/_ref/darwin_on_hip not built (needs /root/reference at build time)")
@@ -60,7 +61,7 @@ for label, env in (("as it is (two calls per thread, one after the other)", {}),
         e.update(env)
         e["GACT_HIP_TIME"] = "1"
         best = None
-        for rep in range(2):
+        for rep in range(reps):
             t0 = time.time()
             p = subprocess.run([exe, "reads.fasta", "reads.fasta", str(threads), "32", "64"], cwd=d, env=e, capture_output=True, text=True, timeout=900)
             wall = time.time() - t0

@@ -178,7 +178,7 @@ int gact_hip_dsoft_query(gact_hip_engine *e, int slot, int32_t first_query, int3
     }
     // staging area of the candidates: a guess, corrected from the exact counts if it proves too small
     size_t temp_guess = (size_t)n_tasks * 32 + (1u << 20);
-    if (const char *g = getenv("GACT_HIP_DSOFT_TEMP_CAP")) temp_guess = (size_t)std::max(1L, atol(g));
+    if (const char *g = opt_env("dsoft_temp_cap")) temp_guess = (size_t)std::max(1L, atol(g));
     if (d.counts.reserve(n_tasks) || d.task_base.reserve(n_tasks) || d.out_base.reserve(n_tasks) ||
         d.temp.reserve(temp_guess))
         return fail(GACT_HIP_ENOMEM, "device allocation failed");

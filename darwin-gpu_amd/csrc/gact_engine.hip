@@ -229,6 +229,70 @@ struct DsoftState {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// Every switch this library reads, in ONE table: INTEGRATION.md 7 prints it, gact_hip_options_describe
+// returns it, tests/test_cabi.py keeps the three in step.  A switch is read from its environment variable once, in
+// gact_hip_create (`when` c), and -- where it is safe on a live engine -- also taken by gact_hip_set_option under its name
+// (`when` l).  Classes: k = which kernels run (the tests reach every kernel family through these; no record depends on any
+// of them), s = scheduling, d = diagnostic / tuning: read only by builds with -DGACT_EXPERIMENTS (gact_hip_create says so on
+// stderr), ignored by the default build.
+struct OptionDef { const char *name, *env; char when, klass; const char *doc; };
+static const OptionDef kOptions[] = {
+    {"force_int32", "GACT_HIP_FORCE_INT32", 'c', 'k', "the int32 chain kernel alone (one launch), whatever the scoring allows"},
+    {"force_int32_seed", "GACT_HIP_FORCE_INT32_SEED", 'c', 'k', "int32 seed launch in front of the packed main launch"},
+    {"force_uniform", "GACT_HIP_FORCE_UNIFORM", 'c', 'k', "uniform instead of split (two-region) column layout"},
+    {"force_wide", "GACT_HIP_FORCE_WIDE", 'c', 'k', "the wide layout (32 lanes per tile pair) for every main launch"},
+    {"no_wide", "GACT_HIP_NO_WIDE", 'c', 'k', "never the wide layout"},
+    {"no_tagged", "GACT_HIP_NO_TAGGED", 'c', 'k', "explicit pointer comparisons instead of tagged scores"},
+    {"no_lin", "GACT_HIP_NO_LIN", 'c', 'k', "the affine passes also for linear scorings (gact_lin.hpp off)"},
+    {"no_aff", "GACT_HIP_NO_AFF", 'c', 'k', "round 1's tagged affine pass instead of the drifted one (gact_aff.hpp off)"},
+    {"no_roles", "GACT_HIP_NO_ROLES", 'c', 'k', "the split linear-gap main launch as one-wave-does-all (gact_roles.hpp off); live: roles"},
+    {"roles", nullptr, 'l', 'k', "1 / 0: DP waves + walker waves for the split linear-gap main launch (engines created with them)"},
+    {"no_routing", "GACT_HIP_NO_ROUTING", 'c', 'k', "a set with a non-ACGT byte moves the whole launch onto the raw-byte kernels"},
+    {"no_side_lane", "GACT_HIP_NO_SIDE_LANE", 'c', 's', "routed raw-byte launches after the 2-bit ones instead of beside them"},
+    {"band", "GACT_HIP_BAND", 'c', 'k', "width of the stored pointer band in columns (default 48; 0: the whole window)"},
+    {"poison_ws", "GACT_HIP_POISON_WS", 'c', 'k', "<seed>: seeded garbage over the traceback workspace before every launch (tests)"},
+    {"no_overlap", "GACT_HIP_NO_OVERLAP", 'c', 's', "seed launch, then one main launch, always; live: overlap_seed"},
+    {"overlap_seed", nullptr, 'l', 's', "1 / 0: ordered, overlapped seeding of large runs on an idle engine"},
+    {"no_crit_lane", "GACT_HIP_NO_CRIT_LANE", 'c', 's', "no wide launch beside the split one for runs of 1-1.5 chains per tile slot"},
+    {"crit_lane_always", "GACT_HIP_CRIT_LANE_ALWAYS", 'c', 's', "... also for runs of up to four chains per tile slot"},
+    {"no_shared_hint", "GACT_HIP_NO_SHARED_HINT", 'c', 's', "a launch made while another slot runs may take the wide layout"},
+    {"runs_in_flight", nullptr, 'l', 's', "1: the caller keeps several runs in flight (every launch takes the throughput layout)"},
+    {"no_combine", "GACT_HIP_NO_COMBINE", 'c', 's', "runs of several threads are never merged into one launch; live: combine"},
+    {"combine", nullptr, 'l', 's', "1 / 0: the call combiner"},
+    {"combine_window_us", "GACT_HIP_COMBINE_US", 'l', 's', "how long a leader waits for the other feeder threads (default 1000)"},
+    {"sdma_copies", "GACT_HIP_SDMA_COPIES", 'c', 's', "candidate lists and records through hipMemcpyAsync instead of a copy kernel"},
+    {"dsoft_temp_cap", "GACT_HIP_DSOFT_TEMP_CAP", 'c', 'k', "initial size of the device filter's candidate staging area (tests: forces the regrow path)"},
+    {"rccl_lib", "GACT_HIP_RCCL_LIB", 'c', 's', "<file>: the RCCL library gact_hip_comm_create loads"},
+    // diagnostic / tuning: -DGACT_EXPERIMENTS builds only
+    {"no_aff_seed", "GACT_HIP_NO_AFF_SEED", 'c', 'd', "round 1's packed seed pass for affine scorings"},
+    {"lane_blocks", "GACT_HIP_LANE_BLOCKS", 'c', 'd', "<n>: blocks of the critical lane"},
+    {"lane_small", "GACT_HIP_LANE_SMALL", 'c', 'd', "<f>: the lane also instead of the all-wide launch, for runs of at least f/2 chains per lane tile"},
+    {"no_chain_prio", "GACT_HIP_NO_CHAIN_PRIO", 'c', 'd', "all DP passes at issue priority 0"},
+    {"static_prio", "GACT_HIP_STATIC_PRIO", 'c', 'd', "fixed priority thresholds instead of the ranking against the longest running chain"},
+    {"rank16", "GACT_HIP_RANK16", 'c', 'd', "the ranking's two thresholds in sixteenths, hi << 8 | mid (default 12, 8)"},
+    {"team_when_shared", "GACT_HIP_TEAM_WHEN_SHARED", 'c', 'd', "look-ahead walker in split launches that share the machine"},
+    {"wide_blocks_per_cu", "GACT_HIP_WIDE_BLOCKS_PER_CU", 'c', 'd', "<n>: resident blocks per CU of the wide launch"},
+    {"band_quantum", "GACT_HIP_BAND_QUANTUM", 'c', 'd', "<1|4|8>: lanes store their band in aligned groups"},
+    {"lin_blocks", "GACT_HIP_LIN_BLOCKS", 'c', 'd', "<n>: a smaller persistent grid for the one-wave-does-all split linear-gap launch"},
+    {"role_blocks", "GACT_HIP_ROLE_BLOCKS", 'c', 'd', "<n>: a smaller persistent grid for the role launch"},
+    {"trace", "GACT_HIP_TRACE", 'c', 'd', "every launch of a run named on stderr and waited for"},
+    {"trace_upload", "GACT_HIP_TRACE_UPLOAD", 'c', 'd', "stamps inside candidates_upload / _fetch on stderr"},
+};
+// the value of a switch's environment variable (null: unset -- or a diagnostic switch in a default build)
+static const char *opt_env(const char *name)
+{
+    for (const OptionDef &o : kOptions)
+        if (!strcmp(o.name, name)) {
+#ifndef GACT_EXPERIMENTS
+            if (o.klass == 'd') return nullptr;
+#endif
+            return o.env ? getenv(o.env) : nullptr;
+        }
+    fprintf(stderr, "[gact_hip] internal: switch '%s' is not in the option table\n", name);
+    abort();
+}
+
 // The call combiner (round 4).  The reference's callers are N feeder threads, each with its own GPU_storage, all
 // calling GACT_Batch at about the same time (darwin.cpp:408-433,619-629).  One persistent launch per call meant N grids
 // queueing for the CUs, each with an N-th of the candidates and no load balancing inside it: 3,957 GCUPS at 8 feeders
@@ -658,7 +722,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
 
     // one seed launch + (packed kernels) one main launch over `count` candidates at most
     // GACT_HIP_TRACE: every launch named on stderr and waited for (a faulting kernel is the last one named)
-    static const bool trace = getenv("GACT_HIP_TRACE") != nullptr;
+    static const bool trace = opt_env("trace") != nullptr;
     auto traced = [&](const Lane &ln, const char *what, int blocks, int count) -> int {
         if (!trace) return 0;
         fprintf(stderr, "[gact_hip] %s: %d blocks, %d candidates ... ", what, blocks, count);
@@ -1142,40 +1206,40 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->kp.thr = p->first_tile_score_threshold;
     e->kp.ws_words = (e->C == 20) ? gact::Geometry<20>::kWsWords : gact::Geometry<32>::kWsWords;
     e->p16 = !big && gact::p16_scoring_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
-             getenv("GACT_HIP_FORCE_INT32") == nullptr;
+             opt_env("force_int32") == nullptr;
     e->split = e->p16 && e->C == 20 && e->kp.early <= gact::GeometrySplit<7, 13>::W2 &&
-               getenv("GACT_HIP_FORCE_UNIFORM") == nullptr;
+               opt_env("force_uniform") == nullptr;
     e->tagged = e->p16 && gact::p16_tagged_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
-                getenv("GACT_HIP_NO_TAGGED") == nullptr;
+                opt_env("no_tagged") == nullptr;
     e->lin = e->tagged && gact::p16_lin_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
-             getenv("GACT_HIP_NO_LIN") == nullptr;
+             opt_env("no_lin") == nullptr;
     e->aff = e->tagged && e->split && !e->lin && gact::p16_aff_ok(p->tile_size, p->match, p->mismatch, p->gap_open, p->gap_extend) &&
-             getenv("GACT_HIP_NO_AFF") == nullptr;
-    e->aff_seed = getenv("GACT_HIP_NO_AFF_SEED") == nullptr;
-    e->kernel_copies = getenv("GACT_HIP_SDMA_COPIES") == nullptr;
-    e->crit_lane = getenv("GACT_HIP_NO_CRIT_LANE") == nullptr;
-    e->crit_lane_always = getenv("GACT_HIP_CRIT_LANE_ALWAYS") != nullptr;
-    if (const char *v = getenv("GACT_HIP_LANE_BLOCKS")) e->lane_blocks = std::max(0, atoi(v));
-    if (const char *v = getenv("GACT_HIP_LANE_SMALL")) { e->lane_small = atoi(v) > 0; e->lane_small_factor = std::max(1, atoi(v)); }
-    e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && getenv("GACT_HIP_FORCE_INT32_SEED") == nullptr;
-    e->chain_prio = getenv("GACT_HIP_NO_CHAIN_PRIO") == nullptr;
-    e->route_other = getenv("GACT_HIP_NO_ROUTING") == nullptr;
-    e->side_lane = getenv("GACT_HIP_NO_SIDE_LANE") == nullptr;
-    e->shared_hint = getenv("GACT_HIP_NO_SHARED_HINT") == nullptr;
-    e->overlap_seed = getenv("GACT_HIP_NO_OVERLAP") == nullptr;
-    e->roles = getenv("GACT_HIP_NO_ROLES") == nullptr;
-    e->team_when_shared = getenv("GACT_HIP_TEAM_WHEN_SHARED") != nullptr;
-    e->static_prio = getenv("GACT_HIP_STATIC_PRIO") != nullptr;
-    if (const char *v = getenv("GACT_HIP_RANK16")) e->rank16 = atoi(v);
-    if (const char *v = getenv("GACT_HIP_POISON_WS")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
-    e->wide = getenv("GACT_HIP_FORCE_WIDE") ? 1 : getenv("GACT_HIP_NO_WIDE") ? -1 : 0;
-    if (const char *v = getenv("GACT_HIP_WIDE_BLOCKS_PER_CU")) e->wide_blocks_per_cu = atoi(v);
+             opt_env("no_aff") == nullptr;
+    e->aff_seed = opt_env("no_aff_seed") == nullptr;
+    e->kernel_copies = opt_env("sdma_copies") == nullptr;
+    e->crit_lane = opt_env("no_crit_lane") == nullptr;
+    e->crit_lane_always = opt_env("crit_lane_always") != nullptr;
+    if (const char *v = opt_env("lane_blocks")) e->lane_blocks = std::max(0, atoi(v));
+    if (const char *v = opt_env("lane_small")) { e->lane_small = atoi(v) > 0; e->lane_small_factor = std::max(1, atoi(v)); }
+    e->seed16 = e->p16 && gact::p16_argmax_ok(p->tile_size, p->match) && opt_env("force_int32_seed") == nullptr;
+    e->chain_prio = opt_env("no_chain_prio") == nullptr;
+    e->route_other = opt_env("no_routing") == nullptr;
+    e->side_lane = opt_env("no_side_lane") == nullptr;
+    e->shared_hint = opt_env("no_shared_hint") == nullptr;
+    e->overlap_seed = opt_env("no_overlap") == nullptr;
+    e->roles = opt_env("no_roles") == nullptr;
+    e->team_when_shared = opt_env("team_when_shared") != nullptr;
+    e->static_prio = opt_env("static_prio") != nullptr;
+    if (const char *v = opt_env("rank16")) e->rank16 = atoi(v);
+    if (const char *v = opt_env("poison_ws")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
+    e->wide = opt_env("force_wide") ? 1 : opt_env("no_wide") ? -1 : 0;
+    if (const char *v = opt_env("wide_blocks_per_cu")) e->wide_blocks_per_cu = atoi(v);
     e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;
     // pointer words of the linear-gap main launch are stored within `band` columns of the diagonal through a tile's (R, Q);
     // a walk that comes within a refill of its edge has its tile run again with the whole window (exact either way).
     // GACT_HIP_BAND=<n>: another width (tests: a narrow one exercises the second runs); 0: the whole window, as before round 4
     e->kp.band = gact::kLinBandDefault;
-    if (const char *v = getenv("GACT_HIP_BAND")) {
+    if (const char *v = opt_env("band")) {
         const int b = atoi(v);
         e->kp.band = b <= 0 ? 0 : std::max(b, gact::kLinBandMin);
     }
@@ -1183,7 +1247,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     // lanes store in aligned groups of 1, 4 or 8 (64 / 128 bytes of a workspace row): bits 16.. of kp.band
     {
         int q = gact::kLinBandQuantum;
-        if (const char *v = getenv("GACT_HIP_BAND_QUANTUM")) q = atoi(v);
+        if (const char *v = opt_env("band_quantum")) q = atoi(v);
         q = q >= 8 ? 8 : q >= 4 ? 4 : q >= 2 ? 2 : 1;
         if (e->kp.band) e->kp.band |= q << 16;
     }
@@ -1224,7 +1288,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         e->lin_grid_blocks = std::max(e->grid_blocks, lb * e->prop.multiProcessorCount);
         // GACT_HIP_LIN_BLOCKS=<n>: a smaller persistent grid for the split linear-gap launch (measurements: fewer resident
         // tiles = a smaller live pointer footprint)
-        if (const char *v = getenv("GACT_HIP_LIN_BLOCKS")) e->lin_grid_blocks = std::max(1, std::min(atoi(v), e->lin_grid_blocks));
+        if (const char *v = opt_env("lin_blocks")) e->lin_grid_blocks = std::max(1, std::min(atoi(v), e->lin_grid_blocks));
         int wb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wb, gact::extend_p16_kernel<gact::WideLayoutLin, false>, gact::kBlockThreads, 0) !=
             hipSuccess) {
@@ -1248,7 +1312,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
             return fail(GACT_HIP_EDEVICE, "hipOccupancyMaxActiveBlocksPerMultiprocessor failed");
         }
         e->role_grid_blocks = std::max(1, std::min(rb, rb2)) * e->prop.multiProcessorCount;
-        if (const char *v = getenv("GACT_HIP_ROLE_BLOCKS")) e->role_grid_blocks = std::max(1, std::min(atoi(v), e->role_grid_blocks));
+        if (const char *v = opt_env("role_blocks")) e->role_grid_blocks = std::max(1, std::min(atoi(v), e->role_grid_blocks));
     }
     e->roles = e->role_grid_blocks > 0;
     e->aff_grid_blocks = e->grid_blocks;
@@ -1286,8 +1350,8 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         e->ws_words_total = (size_t)e->big_blocks * per_block / sizeof(uint32_t);
     }
     e->n_user = p->n_slots;
-    e->cb.enabled = getenv("GACT_HIP_NO_COMBINE") == nullptr && !big;
-    if (const char *v = getenv("GACT_HIP_COMBINE_US")) e->cb.window_us = std::max(0, atoi(v));
+    e->cb.enabled = opt_env("no_combine") == nullptr && !big;
+    if (const char *v = opt_env("combine_window_us")) e->cb.window_us = std::max(0, atoi(v));
     e->cb.n_merge = (e->cb.enabled && p->n_slots > 1) ? 2 : 0;
     e->slots.resize(p->n_slots + e->cb.n_merge);            // (never resized again: references into it stay good)
     // (the first merge slot with the callers' slots: its 1.3 GB would otherwise be allocated inside the first merged launch)
@@ -1300,7 +1364,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
 void gact_hip_destroy(gact_hip_engine *e)
 {
     if (!e) return;
-    if (getenv("GACT_HIP_TRACE") && e->cb.merged_launches)
+    if (opt_env("trace") && e->cb.merged_launches)
         fprintf(stderr, "[gact_hip] combiner: %ld merged launches carried %ld runs, %ld times a group that had come apart was joined again\n", e->cb.merged_launches, e->cb.merged_runs, e->cb.rejoins);
     (void)hipSetDevice(e->params.device_id);
     for (auto &sl : e->slots) {
@@ -1532,7 +1596,7 @@ int gact_hip_candidates_upload(gact_hip_engine *e, int slot, int32_t n, const ga
     if (rc) return rc;
     if (n < 0 || (n > 0 && !cands)) return fail(GACT_HIP_EINVAL, "candidates_upload: bad arguments");
     // GACT_HIP_TRACE_UPLOAD: where an upload's time goes, per call, on stderr (microseconds since the call began)
-    static const bool trace_up = getenv("GACT_HIP_TRACE_UPLOAD") != nullptr;
+    static const bool trace_up = opt_env("trace_upload") != nullptr;
     const auto tu0 = std::chrono::steady_clock::now();
     long tu[6] = {0, 0, 0, 0, 0, 0};
     auto mark = [&](int k) { if (trace_up) tu[k] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tu0).count(); };
@@ -1892,7 +1956,7 @@ int gact_hip_candidates_fetch(gact_hip_engine *e, int slot, int32_t n, gact_over
         HIP_TRY(hipStreamSynchronize(sl.stream));
         return 0;
     }
-    static const bool trace_fetch = getenv("GACT_HIP_TRACE_UPLOAD") != nullptr;       // (the same switch as the upload's trace)
+    static const bool trace_fetch = opt_env("trace_upload") != nullptr;       // (the same switch as the upload's trace)
     const auto tf0 = std::chrono::steady_clock::now();
     long tf[3] = {0, 0, 0};
     auto fmark = [&](int k) { if (trace_fetch) tf[k] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - tf0).count(); };
@@ -2129,8 +2193,32 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
     } else if (n == "combine_window_us") {
         std::lock_guard<std::mutex> lk(e->cb.mu);
         e->cb.window_us = std::max(0, (int)value);
-    } else return fail(GACT_HIP_EINVAL, "set_option: unknown option '%s'", name);
+    } else if (n == "roles") {
+        if (value != 0 && e->role_grid_blocks <= 0) return fail(GACT_HIP_EINVAL, "set_option: this engine was created without the role launch");
+        e->roles = value != 0;
+    } else {
+        for (const OptionDef &o : kOptions)
+            if (n == o.name) return fail(GACT_HIP_EINVAL, "set_option: '%s' is read once, in gact_hip_create%s%s", name, o.env ? ", from " : "", o.env ? o.env : "");
+        return fail(GACT_HIP_EINVAL, "set_option: unknown option '%s'", name);
+    }
     return 0;
+}
+
+int64_t gact_hip_options_describe(char *buf, int64_t cap)
+{
+    std::string t;
+    for (const OptionDef &o : kOptions) {
+        t += o.name; t += " | "; t += o.env ? o.env : "-"; t += " | ";
+        t += o.when == 'l' ? "live (gact_hip_set_option)" : "gact_hip_create"; t += " | ";
+        t += o.klass == 'k' ? "kernels" : o.klass == 's' ? "scheduling" : "diagnostic (-DGACT_EXPERIMENTS)";
+        t += " | "; t += o.doc; t += "\n";
+    }
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>((size_t)cap - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)t.size() + 1;
 }
 
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot)

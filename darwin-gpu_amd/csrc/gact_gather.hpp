@@ -56,7 +56,7 @@ int load_rccl()
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.lib) return 0;
     // a copy that is in the process already wins (RTLD_NOLOAD): one RCCL per process
-    const char *names[] = {getenv("GACT_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    const char *names[] = {opt_env("rccl_lib"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *lib = nullptr;
     for (const char *nm : names)
         if (nm && *nm && (lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;

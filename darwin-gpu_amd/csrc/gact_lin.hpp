@@ -310,9 +310,6 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         bd.lo[0] = bd.lo[1] = lo_.lo[0]; bd.hi[0] = bd.hi[1] = hi_.hi[0];
         bd.full[0] = fullA | (b <= 0); bd.full[1] = fullB | (b <= 0);
     }
-#if GACT_EXP_NO_STORE
-    if (kc.one != 0x7ffe7ffeu) { bd.full[0] = bd.full[1] = false; bd.lo[0] = bd.lo[1] = 1; bd.hi[0] = bd.hi[1] = 0; }   // (timing experiment: no stores)
-#endif
     // whole blocks of eight steps, each followed by its flush (an `if ((k & 7) == 7)` inside one loop is
     // if-converted by the compiler: the re-pairing v_perm of the flush would then run at every step)
     int k = 0;
@@ -353,7 +350,7 @@ __device__ __forceinline__ uint32_t dp_pass_lin(const P16Consts &kc, const int g
 {
     constexpr int NW = LinWords<C>::kWords, QD = LinWords<C>::kUint4;
     // col_from: first column (1-based) a walk can reach in either tile: lanes left of it keep their words
-    const bool store = (AMAX || gl * C + C >= col_from) && (!GACT_EXP_NO_STORE || kc.one == 0x7ffe7ffeu);
+    const bool store = AMAX || gl * C + C >= col_from;
     // band (non-first tiles, see LinBand): the lane's columns gl C + 1 .. gl C + C are Q - gl C - C .. Q - gl C - 1 away from
     // column Q, whose lane is (Q - 1) / C
     LinBand bd;

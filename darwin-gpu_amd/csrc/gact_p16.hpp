@@ -44,18 +44,14 @@ __device__ unsigned long long g_wave_cycles[4096];
 #define GACT_SEED_WALK_TEAM 1
 #endif
 
-// timing experiments (results are WRONG by design): no traceback walk / no pointer stores.  Only with -DGACT_EXPERIMENTS,
-// and gact_hip_create says so on stderr (gact_engine.hip); the experiments of rounds 2-3 that lived in the flush are in
-// the history of this file and in DESIGN.md 5.0, not here
+// timing experiment (results are WRONG by design): no traceback walk.  Only with -DGACT_EXPERIMENTS, and gact_hip_create
+// says so on stderr (gact_engine.hip); the store experiments of rounds 2-4 are in the history of gact_lin.hpp and in
+// DESIGN.md 5.0, not in the sources
 #ifndef GACT_EXPERIMENTS
 #undef GACT_EXP_FAKE_WALK
-#undef GACT_EXP_NO_STORE
 #endif
 #ifndef GACT_EXP_FAKE_WALK
 #define GACT_EXP_FAKE_WALK 0
-#endif
-#ifndef GACT_EXP_NO_STORE
-#define GACT_EXP_NO_STORE 0
 #endif
 
 constexpr int kNegInf16 = -16384;

@@ -210,7 +210,22 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
            "gact_hip_candidates_download", "gact_hip_derive_revcomp", "gact_hip_register_output",
            "gact_hip_unregister_output", "gact_hip_set_option", "gact_hip_prepare",
-           "gact_hip_comm_create", "gact_hip_comm_gather_lines", "gact_hip_comm_destroy")
+           "gact_hip_comm_create", "gact_hip_comm_gather_lines", "gact_hip_comm_destroy", "gact_hip_options_describe")
+
+
+def options_table():
+    """[(name, environment variable or None, when, class, doc)] of every switch libgact_hip.so reads (no device needed)"""
+    lib = load()
+    lib.gact_hip_options_describe.restype = C.c_int64
+    lib.gact_hip_options_describe.argtypes = [C.c_char_p, C.c_int64]
+    n = lib.gact_hip_options_describe(None, 0)
+    buf = C.create_string_buffer(int(n))
+    lib.gact_hip_options_describe(buf, n)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        name, env, when, klass, doc = [x.strip() for x in line.split(" | ", 4)]
+        rows.append((name, None if env == "-" else env, when, klass, doc))
+    return rows
 
 
 class Engine:

@@ -306,8 +306,16 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *   "combine_window_us"  how long the first of such runs waits for the others at most (default 1000)
  *   "runs_in_flight"     1: the caller keeps several runs in flight on this engine (a pipeline of steps, one slot each): every
  *                        launch takes the layout with the better throughput.  0 (default): the engine looks at the other slots'
- *                        events when a run is launched, which the first launches of a pipeline answer differently from run to run */
+ *                        events when a run is launched, which the first launches of a pipeline answer differently from run to run
+ *   "roles"              1 (default for engines created with it): the split linear-gap main launch runs as DP waves + walker
+ *                        waves (gact_hip_run_stats.role_waves); 0: one wave does everything for its tiles, as before round 5
+ * Every other switch of the library is read once, in gact_hip_create, from an environment variable; set_option names the
+ * variable when asked for one of those.  The whole table: gact_hip_options_describe, INTEGRATION.md 7. */
 int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value);
+/* The table of every switch the library reads, one line per switch: `name | environment variable | when it is read |
+ * class | what it does`.  Writes at most cap bytes (NUL-terminated) into buf, returns the size the whole table needs.
+ * No engine, no device. */
+int64_t gact_hip_options_describe(char *buf, int64_t cap);
 
 /* device address of the slot's gact_overlap array (for an RCCL gather) */
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);

@@ -106,3 +106,28 @@ def test_gather_entry_points_refuse_bad_arguments_and_the_line_record_is_the_pyt
     subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), "-o", str(tmp_path / "line"), str(tmp_path / "line.c")])
     got = [int(v) for v in subprocess.check_output([str(tmp_path / "line")]).split()]
     assert got == [dist.LINE_BYTES] + [dist.LINE_DTYPE.fields[n][1] for n in names]
+
+
+def test_every_switch_of_the_library_is_in_the_one_table_and_in_the_docs():
+    """the library's switches live in ONE table (csrc/gact_engine.hip kOptions, gact_hip_options_describe);
+    INTEGRATION.md 7 prints it; nothing under csrc/ reads a GACT_HIP_* variable outside it."""
+    import re
+    from gact_amd import engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = engine.options_table()
+    assert len(rows) >= 30 and len({r[0] for r in rows}) == len(rows)
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    for name, env, when, klass, text in rows:
+        assert "`%s`" % name in doc, "INTEGRATION.md 7 lacks the switch %s" % name
+        if env:
+            assert "`%s`" % env in doc, "INTEGRATION.md 7 lacks %s" % env
+    envs = {r[1] for r in rows if r[1]}
+    src_dir = os.path.join(root, "darwin-gpu_amd", "csrc")
+    for fn in sorted(os.listdir(src_dir)):
+        text = open(os.path.join(src_dir, fn)).read()
+        for m in re.finditer(r'getenv\("(GACT_HIP_[A-Z0-9_]+)"\)', text):
+            raise AssertionError("%s reads %s with getenv: switches go through the option table (opt_env)" % (fn, m.group(1)))
+        for m in re.finditer(r'"(GACT_HIP_[A-Z0-9_]+)"', text):
+            assert m.group(1) in envs, "%s names %s, which is not in the option table" % (fn, m.group(1))
+    # diagnostic switches are dead in the default build: the table says so, and the default build is what is tested here
+    assert any(k.startswith("diagnostic") for _, _, _, k, _ in rows)

@@ -246,8 +246,7 @@ static const OptionDef kOptions[] = {
     {"no_tagged", "GACT_HIP_NO_TAGGED", 'c', 'k', "explicit pointer comparisons instead of tagged scores"},
     {"no_lin", "GACT_HIP_NO_LIN", 'c', 'k', "the affine passes also for linear scorings (gact_lin.hpp off)"},
     {"no_aff", "GACT_HIP_NO_AFF", 'c', 'k', "round 1's tagged affine pass instead of the drifted one (gact_aff.hpp off)"},
-    {"no_roles", "GACT_HIP_NO_ROLES", 'c', 'k', "the split linear-gap main launch as one-wave-does-all (gact_roles.hpp off); live: roles"},
-    {"roles", nullptr, 'l', 'k', "1 / 0: DP waves + walker waves for the split linear-gap main launch (engines created with them)"},
+    {"roles", "GACT_HIP_ROLES", 'l', 'k', "1: the split linear-gap main launch as DP waves + walker waves (gact_roles.hpp; default 0: measured no faster, DESIGN 3.13)"},
     {"no_routing", "GACT_HIP_NO_ROUTING", 'c', 'k', "a set with a non-ACGT byte moves the whole launch onto the raw-byte kernels"},
     {"no_side_lane", "GACT_HIP_NO_SIDE_LANE", 'c', 's', "routed raw-byte launches after the 2-bit ones instead of beside them"},
     {"band", "GACT_HIP_BAND", 'c', 'k', "width of the stored pointer band in columns (default 48; 0: the whole window)"},
@@ -356,7 +355,7 @@ struct gact_hip_engine {
     int seed_grid_blocks = 0;   // persistent grid of the packed seed kernel (2 waves per SIMD)
     int seed_lin_grid_blocks = 0;       // ... of its linear-gap form (3)
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
-    bool roles = true;          // GACT_HIP_NO_ROLES unset: the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
+    bool roles = false;         // GACT_HIP_ROLES=1 / set_option "roles": the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
     int role_grid_blocks = 0;   // ... and its persistent grid (blocks of kRoleThreads)
     int aff_grid_blocks = 0;    // ... of the drifted affine split launch (two blocks per CU)
     int wide_lin_grid_blocks = 0;       // ... of the linear-gap wide launch
@@ -1227,7 +1226,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     e->side_lane = opt_env("no_side_lane") == nullptr;
     e->shared_hint = opt_env("no_shared_hint") == nullptr;
     e->overlap_seed = opt_env("no_overlap") == nullptr;
-    e->roles = opt_env("no_roles") == nullptr;
+    e->roles = opt_env("roles") != nullptr && atoi(opt_env("roles")) != 0;
     e->team_when_shared = opt_env("team_when_shared") != nullptr;
     e->static_prio = opt_env("static_prio") != nullptr;
     if (const char *v = opt_env("rank16")) e->rank16 = atoi(v);
@@ -1303,7 +1302,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     }
     if (!e->lin) e->wide_lin_grid_blocks = e->grid_blocks;
     e->role_grid_blocks = 0;
-    if (e->lin && e->split && e->C == 20 && e->roles) {
+    if (e->lin && e->split && e->C == 20) {
         using RL = gact::SplitLayoutLin<7, 13>;
         int rb = 0, rb2 = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&rb, gact::extend_roles_kernel<RL, false>, gact::kRoleThreads, 0) != hipSuccess ||
@@ -1314,7 +1313,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         e->role_grid_blocks = std::max(1, std::min(rb, rb2)) * e->prop.multiProcessorCount;
         if (const char *v = opt_env("role_blocks")) e->role_grid_blocks = std::max(1, std::min(atoi(v), e->role_grid_blocks));
     }
-    e->roles = e->role_grid_blocks > 0;
+    e->roles = e->roles && e->role_grid_blocks > 0;
     e->aff_grid_blocks = e->grid_blocks;
     if (e->aff) {
         int ab = 0;
@@ -1329,10 +1328,10 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
         for (int *g : {&e->grid_blocks, &e->seed_grid_blocks, &e->seed_lin_grid_blocks, &e->lin_grid_blocks, &e->wide_lin_grid_blocks, &e->aff_grid_blocks})
             *g = std::max(1, std::min(*g, (int)p->max_blocks));
         // (a role block is twelve waves where the others are four)
-        if (e->roles) e->role_grid_blocks = std::max(1, std::min(e->role_grid_blocks, (int)p->max_blocks * 4 / (gact::kRoleDp + gact::kRoleWalk)));
+        if (e->role_grid_blocks > 0) e->role_grid_blocks = std::max(1, std::min(e->role_grid_blocks, (int)p->max_blocks * 4 / (gact::kRoleDp + gact::kRoleWalk)));
     }
     e->ws_words_total = ws_words_for(std::max(std::max(e->grid_blocks, e->aff_grid_blocks), std::max(e->lin_grid_blocks, e->wide_lin_grid_blocks)));
-    if (e->roles) {
+    if (e->role_grid_blocks > 0) {
         // the role launch lays its pointer words out by wave and bank (gact_roles.hpp); overlapped seeding puts two thirds of
         // its blocks in front of a seed launch's and a main launch's share of the workspace
         using RL = gact::SplitLayoutLin<7, 13>;
@@ -1341,6 +1340,7 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
                                      gact::role_ws_words<RL>(r1) + std::max(gact::role_ws_words<RL>(r2), ws_words_for(e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3)));
         if ((need + 64) * sizeof(uint32_t) >= (1ull << 32)) { e->roles = false; e->role_grid_blocks = 0; }
         else e->ws_words_total = std::max(e->ws_words_total, need);
+        // (the launch itself is taken with GACT_HIP_ROLES=1 / set_option "roles"; the grid and the room are there either way)
     }
     if (big) {
         // one pointer matrix per wave (1 MB at 16 columns per lane, 4 MB at 32): at most 2 GiB per slot, two blocks per CU
@@ -2164,7 +2164,7 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates)
                                    e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
                 hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>), dim3(1), dim3(gact::kBlockThreads), 0, st,
                                    e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q2, sl.d_ws);
-                if (e->roles) {
+                if (e->role_grid_blocks > 0) {
                     hipLaunchKernelGGL((gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(1), dim3(gact::kRoleThreads), 0, st,
                                        e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
                     hipLaunchKernelGGL((gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, true>), dim3(1), dim3(gact::kRoleThreads), 0, st,

@@ -15,8 +15,8 @@
 //     by all walking lanes at the same trip, once per eight moves, exactly the cadence of walk_chain_lin.
 //
 // The walk itself is walk_chain_lin's, move for move (same cells, same order, same stop tests, same band rule): the two
-// functions are kept side by side on purpose, the old kernel stays the A/B partner (GACT_HIP_NO_ROLES=1) and the kernel
-// of every other layout.  What changes is where the bases come from: the loader's staging words (the tile's two slices
+// functions are kept side by side on purpose; extend_p16_kernel stays the default (this launch is taken with GACT_HIP_ROLES=1
+// or gact_hip_set_option "roles": measured no faster) and the kernel of every other layout.  What changes is where the bases come from: the loader's staging words (the tile's two slices
 // as they lie in the 2-bit image) stay in LDS until the bank is loaded again, and the walker cuts the two bases of a cell
 // out of them -- the DP wave's unpacked base arrays belong to the other bank by then.
 //

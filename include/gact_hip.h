@@ -307,8 +307,8 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *   "runs_in_flight"     1: the caller keeps several runs in flight on this engine (a pipeline of steps, one slot each): every
  *                        launch takes the layout with the better throughput.  0 (default): the engine looks at the other slots'
  *                        events when a run is launched, which the first launches of a pipeline answer differently from run to run
- *   "roles"              1 (default for engines created with it): the split linear-gap main launch runs as DP waves + walker
- *                        waves (gact_hip_run_stats.role_waves); 0: one wave does everything for its tiles, as before round 5
+ *   "roles"              1: the split linear-gap main launch runs as DP waves + walker waves (gact_hip_run_stats.role_waves);
+ *                        0 (default): one wave does everything for its tiles.  Same records; measured no faster
  * Every other switch of the library is read once, in gact_hip_create, from an environment variable; set_option names the
  * variable when asked for one of those.  The whole table: gact_hip_options_describe, INTEGRATION.md 7. */
 int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value);

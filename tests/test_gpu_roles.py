@@ -47,6 +47,7 @@ def test_role_launch_equals_the_oracle_and_the_old_launch(monkeypatch, reads_and
     rs, cf, cr, want = reads_and_records
     cands = np.concatenate([cf, cr])
     monkeypatch.setenv("GACT_HIP_NO_WIDE", "1")              # (a list this small would take the wide layout)
+    monkeypatch.setenv("GACT_HIP_ROLES", "1")
     eng = engine.Engine()
     _load(eng, rs)
     eng.candidates_upload(cands)
@@ -57,7 +58,7 @@ def test_role_launch_equals_the_oracle_and_the_old_launch(monkeypatch, reads_and
         assert st["role_waves"] and st["layout"] == "packed16-split" and st["linear_gap"], st
         _same(got, want, "role launch, run %d" % rep)
     eng.close()
-    monkeypatch.setenv("GACT_HIP_NO_ROLES", "1")
+    monkeypatch.delenv("GACT_HIP_ROLES")
     eng = engine.Engine()
     _load(eng, rs)
     eng.candidates_upload(cands)
@@ -76,6 +77,7 @@ def test_role_launch_at_every_list_size_around_a_bank(monkeypatch, reads_and_rec
     nf = len(cf)
     monkeypatch.setenv("GACT_HIP_NO_WIDE", "1")
     eng = engine.Engine()
+    eng.set_option("roles", 1)                               # (the live switch)
     _load(eng, rs)
     cands = np.concatenate([cf, cr])
     eng.candidates_upload(cands)
@@ -94,6 +96,7 @@ def test_role_launch_second_runs_through_the_whole_window(monkeypatch, reads_and
     from gact_amd import engine
     rs, cf, cr, want = reads_and_records
     monkeypatch.setenv("GACT_HIP_NO_WIDE", "1")
+    monkeypatch.setenv("GACT_HIP_ROLES", "1")
     monkeypatch.setenv("GACT_HIP_BAND", str(band))
     eng = engine.Engine()
     _load(eng, rs)
@@ -111,6 +114,7 @@ def test_role_launches_of_several_slots_in_flight(monkeypatch, reads_and_records
     from gact_amd import engine
     rs, cf, cr, want = reads_and_records
     monkeypatch.setenv("GACT_HIP_NO_WIDE", "1")
+    monkeypatch.setenv("GACT_HIP_ROLES", "1")
     S = 3
     eng = engine.Engine(n_slots=S)
     _load(eng, rs)

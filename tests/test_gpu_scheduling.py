@@ -283,8 +283,6 @@ def test_the_critical_lane_changes_no_record(monkeypatch):
     blk = workload_block("ecoli10x")
     cands = np.concatenate([blk.cf, blk.cr])
     nf = len(blk.cf)
-    # (the lane belongs to the one-wave-does-all split launch; the role launch of round 5 takes its place by default)
-    monkeypatch.setenv("GACT_HIP_NO_ROLES", "1")
     monkeypatch.setenv("GACT_HIP_NO_CRIT_LANE", "1")
     eng = engine.Engine()
     _load(eng, blk.rs)

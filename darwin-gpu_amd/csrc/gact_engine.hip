@@ -35,6 +35,7 @@
 #include "gact_lin.hpp"
 #include "gact_aff.hpp"
 #include "gact_roles.hpp"
+#include "gact_policy.hpp"
 #include "gact_big.hpp"
 #include "dsoft_device.hpp"
 
@@ -684,6 +685,23 @@ int launch_big_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_fro
     return 0;
 }
 
+// the engine's capabilities as the launch policy sees them (gact_policy.hpp)
+gact_policy::Caps policy_caps(const gact_hip_engine *e)
+{
+    gact_policy::Caps c;
+    c.C = e->C; c.p16 = e->p16; c.seed16 = e->seed16; c.lin = e->lin; c.aff = e->aff; c.aff_seed = e->aff_seed; c.split = e->split; c.tagged = e->tagged;
+    c.mismatch_below_extend = e->params.mismatch < e->params.gap_extend;
+    c.roles = e->roles; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
+    c.lane_small = e->lane_small; c.lane_small_factor = e->lane_small_factor; c.lane_blocks = e->lane_blocks; c.team_when_shared = e->team_when_shared;
+    c.wide = e->wide; c.wide_blocks_per_cu = e->wide_blocks_per_cu; c.cus = e->prop.multiProcessorCount;
+    c.grid_blocks = e->grid_blocks; c.seed_grid_blocks = e->seed_grid_blocks; c.seed_lin_grid_blocks = e->seed_lin_grid_blocks;
+    c.lin_grid_blocks = e->lin_grid_blocks; c.aff_grid_blocks = e->aff_grid_blocks; c.wide_lin_grid_blocks = e->wide_lin_grid_blocks;
+    c.role_grid_blocks = e->role_grid_blocks; c.role_dp_waves = gact::kRoleDp;
+    c.ws_words_per_tile = (size_t)e->kp.ws_words;
+    c.role_ws_words_per_block = gact::role_ws_words<gact::SplitLayoutLin<7, 13>>(1);
+    return c;
+}
+
 // strands: -1 what [first, first + n) and rc_from say; else bit 0 = forward-strand candidates present, bit 1 =
 // reverse-complement ones (merged runs: rc_from == kCompInCand, the strand travels with the candidate)
 template <int C>
@@ -733,26 +751,90 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         return 0;
     };
     // second_set: the pass files and pops its chains in the lane's second set of queues (the raw-byte pass behind the 2-bit
-    // one on the same lane: the first set keeps its counts for the statistics, nothing is cleared between the passes)
+    // one on the same lane: the first set keeps its counts for the statistics, nothing is cleared between the passes).
+    // WHAT the pass runs as -- kernels, grids, sequence -- is gact_policy::plan_pass's answer (gact_policy.hpp: a pure function
+    // of the count and the engine's capabilities); what follows launches it.
     auto run_pass = [&](const Lane &ln, bool raw, const int *list, const int *list_count, int count, bool first_pass, bool second_set = false) -> int {
-        auto grid = [&](int needed, int occupancy_cap) { return std::max(1, std::min(needed, ln.max_blocks ? std::min(occupancy_cap, ln.max_blocks) : occupancy_cap)); };
-        const int groups_needed = e->p16 ? (count + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave)
-                                         : (count + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
-        const int seed_waves = (count + gact::kGroupsPerWave - 1) / gact::kGroupsPerWave;
-        const int seed_blocks = grid((seed_waves + 3) / 4, e->grid_blocks);
-        const int main_blocks = grid((groups_needed + 3) / 4, e->grid_blocks);
+        namespace pol = gact_policy;
+        pol::Inputs in;
+        in.count = count; in.raw = raw; in.listed = list != nullptr; in.second_set = second_set; in.shared_machine = shared_machine;
+        in.own_lane = ln.stream == sl.stream; in.trace = trace; in.poison = e->poison != 0; in.lane_max_blocks = ln.max_blocks;
+        const pol::Plan plan = pol::plan_pass(policy_caps(e), in);
         const gact::SeqSetDev d_rs = rs.dev(raw), d_qf = qf.dev_or(raw, rs), d_qr = qr.dev_or(raw, rs);
         gact::ChainQueues cq = second_set ? second_queues(ln, sl) : queues(ln, sl);
         cq.list = list; cq.list_count = list_count;
         if (trace) {
-            fprintf(stderr, "[gact_hip] pass raw=%d listed=%d side=%d count=%d first=%d n=%d rc_from=%d\n", (int)raw, list != nullptr,
-                    ln.stream != sl.stream, count, first, n, rc_from);
+            fprintf(stderr, "[gact_hip] pass raw=%d listed=%d side=%d count=%d first=%d n=%d rc_from=%d plan=%s\n", (int)raw, list != nullptr,
+                    ln.stream != sl.stream, count, first, n, rc_from, pol::describe(plan).c_str());
             fprintf(stderr, "[gact_hip]   ws %p + %zu MiB, counter %p, cands %p (%zu), overlaps %p, live %p (%zu), states %p (%zu x %zu B)\n", (void *)ln.d_ws,
                     ln.ws_words * 4 >> 20, (void *)ln.d_counter, (void *)sl.cands.p, sl.cands.cap, (void *)sl.overlaps.p, (void *)ln.live,
                     ln.live_cap, (void *)sl.chain_states.p, sl.chain_states.cap, sizeof(gact::ChainState));
             fprintf(stderr, "[gact_hip]   ref raw %p packed %p offsets %p (%lld bases), query %p %p, rc %p %p\n", (void *)rs.d_raw, (void *)rs.d_packed,
                     (void *)rs.d_offsets, (long long)rs.total, (void *)qf.d_raw, (void *)qf.d_packed, (void *)qr.d_raw, (void *)qr.d_packed);
         }
+        using gact::extend_p16_kernel;
+        using RolesL = gact::SplitLayoutLin<7, 13>;
+        // a main launch of the plan's kernel: the same arguments whatever the kernel
+        auto launch_main = [&](pol::MainK k, bool two_sets, int blocks, hipStream_t stream, const gact::ChainQueues &q, uint32_t *ws) -> int {
+            using M = pol::MainK;
+            const dim3 g((unsigned)blocks), b256(gact::kBlockThreads), brole(gact::kRoleThreads);
+#define GACT_LAUNCH_MAIN(KERNEL, BLOCK) hipLaunchKernelGGL(KERNEL, g, BLOCK, 0, stream, kp, e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, q, ws)
+            if constexpr (C == 20) {
+                switch (k) {
+                case M::RolesLin: if (two_sets) GACT_LAUNCH_MAIN((gact::extend_roles_kernel<RolesL, true>), brole); else GACT_LAUNCH_MAIN((gact::extend_roles_kernel<RolesL, false>), brole); break;
+                case M::SplitLin: if (two_sets) GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>), b256); else GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>), b256); break;
+                case M::SplitLinTeam: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutLinTeam<7, 13>, false>), b256); break;
+                case M::WideLin: if (two_sets) GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayoutLin, false, true>), b256); else GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayoutLin, false>), b256); break;
+                case M::SplitAffNeg: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutAff<7, 13, true>, false>), b256); break;
+                case M::SplitAff: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutAff<7, 13, false>, false>), b256); break;
+                default: break;
+                }
+            }
+            switch (k) {
+            case M::WideTaggedRaw: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayoutTagged, true>), b256); break;
+            case M::WideTagged: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayoutTagged, false>), b256); break;
+            case M::WideRaw: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayout, true>), b256); break;
+            case M::Wide: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayout, false>), b256); break;
+            case M::SplitTaggedRaw: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>), b256); break;
+            case M::SplitTagged: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>), b256); break;
+            case M::SplitRaw: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayout<7, 13>, true>), b256); break;
+            case M::Split: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayout<7, 13>, false>), b256); break;
+            case M::UniformTaggedRaw: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, true>), b256); break;
+            case M::UniformTagged: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, false>), b256); break;
+            case M::UniformRaw: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::UniformLayout<C>, true>), b256); break;
+            case M::Uniform: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::UniformLayout<C>, false>), b256); break;
+            default: break;
+            }
+#undef GACT_LAUNCH_MAIN
+            HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        auto launch_seed = [&](pol::SeedK k, int blocks, hipStream_t stream, const gact::ChainQueues &q, uint32_t *ws) -> int {
+            using S = pol::SeedK;
+            const dim3 g((unsigned)blocks), b256(gact::kBlockThreads);
+#define GACT_LAUNCH_SEED(KERNEL) hipLaunchKernelGGL(KERNEL, g, b256, 0, stream, kp, e->kc, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file, sl.overlaps.p, q, ws)
+            if constexpr (C == 20) {
+                switch (k) {
+                case S::P16Lin: GACT_LAUNCH_SEED((gact::seed_p16_kernel<C, false, 1>)); break;
+                case S::P16Aff: GACT_LAUNCH_SEED((gact::seed_p16_kernel<C, false, 2>)); break;
+                case S::P16AffNeg: GACT_LAUNCH_SEED((gact::seed_p16_kernel<C, false, 3>)); break;
+                default: break;
+                }
+            }
+            switch (k) {
+            case S::P16Raw: GACT_LAUNCH_SEED((gact::seed_p16_kernel<C, true>)); break;
+            case S::P16: GACT_LAUNCH_SEED((gact::seed_p16_kernel<C, false>)); break;
+            case S::Int32:
+                hipLaunchKernelGGL((gact::extend_kernel<C>), g, b256, 0, stream, kp, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file,
+                                   sl.overlaps.p, q, e->p16 ? 1 : 0, ws);
+                break;
+            default: break;
+            }
+#undef GACT_LAUNCH_SEED
+            HIP_TRY(hipGetLastError());
+            return 0;
+        };
+        int rc = 0;
         // Overlapped, ordered seeding (round 4).  One at a time a run was: seed launch (every first tile, ~2 ms on ecoli10x) ->
         // main launch, whose longest chains -- the ones that end last -- started only then.  Here the candidates are first
         // sorted by the length class of the chain they can make (two tiny launches), and
@@ -763,218 +845,74 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         // Every producer / consumer pair of a set of queues is still separated by a launch boundary (or by the flag written
         // in stream order behind seed launch B plus an acquire, extend_p16_kernel): nothing is handed over between running
         // launches.  The two thirds / one third of the workspace go with the blocks.
-        if constexpr (C == 20) {
-            const int narrow_slots0 = e->lin_grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
-            if (e->overlap_seed && !raw && !list && !trace && !e->poison && e->seed16 && e->lin && e->split && e->wide <= 0 &&
-                !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 && count >= narrow_slots0 + narrow_slots0 / 2 &&
-                count <= 4 * narrow_slots0 &&         // (a larger run: the seed phase is a few per cent of it, and two main launches
-                                                      //  side by side cost about as much -- pacbio50mb, 334 k candidates: +1.4 %)
-                e->lin_grid_blocks >= 3) {
-                { int arc = ensure_aux_stream(sl); if (arc) return arc; }
-                const int ob = std::max(1, std::min((count + 255) / 256, 1024));
-                hipLaunchKernelGGL(gact::order_hist_kernel, dim3(ob), dim3(256), 0, ln.stream, sl.cands.p, first, count, rc_from, d_rs.offsets,
-                                   d_qf.offsets, d_qr.offsets, kp.early, ln.d_counter + kOrderHist);
-                hipLaunchKernelGGL(gact::order_scatter_kernel, dim3(ob), dim3(256), 0, ln.stream, sl.cands.p, first, count, rc_from,
-                                   d_rs.offsets, d_qf.offsets, d_qr.offsets, kp.early, ln.d_counter + kOrderHist,
-                                   ln.d_counter + kOrderCursor, sl.order.p);
-                HIP_TRY(hipGetLastError());
-                const int main1_blocks = e->lin_grid_blocks * 2 / 3, main2_blocks = e->lin_grid_blocks - main1_blocks;
-                // (seed launch B runs on a third of the machine, and until it has ended main launch 1 gets no new chains: it is
-                //  given what it can seed in a few milliseconds, two candidates per resident tile slot; a larger run seeds the
-                //  rest in launch A)
-                const int nA = std::max(std::min(count, main1_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots),
-                                        count - 2 * narrow_slots0);
-                // (the role launch, gact_roles.hpp: blocks of six waves, its own workspace layout)
-                const bool roles = e->roles;
-                const int role1_blocks = e->role_grid_blocks * 2 / 3, role2_blocks = e->role_grid_blocks - role1_blocks;
-                const size_t ws_split = roles ? gact::role_ws_words<gact::SplitLayoutLin<7, 13>>(role1_blocks) : ws_words_for(e, main1_blocks);
-                auto seed_blocks_for = [&](int cnt, int cap) { return std::max(1, std::min(((cnt + 2 * gact::kGroupsPerWave - 1) / (2 * gact::kGroupsPerWave) + 3) / 4, cap)); };
-                auto kseed = gact::seed_p16_kernel<20, false, 1>;
-                auto kmain = gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>;
-                auto kmain_roles = gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, true>;
-                // the critical lane (ChainQueues::leave_longest): main launch 2 in the wide layout -- its third of the blocks
-                // holds 16 tiles a block -- and main launch 1 leaves it that many of the longest chains
-                // (measured on ecoli10x, 2.7 chains per tile slot: a run that size is bound by throughput, and a third of the
-                //  waves in the wide layout cost 12 % of that -- main launches 34-35 ms instead of 29.5-30.3; the lane is for
-                //  runs of fewer chains, below.  GACT_HIP_CRIT_LANE_ALWAYS=1 takes it here too.)
-                const bool lane = !roles && e->crit_lane && e->crit_lane_always && e->wide == 0 && main2_blocks <= e->wide_lin_grid_blocks;
-                auto kmain2 = lane ? gact::extend_p16_kernel<gact::WideLayoutLin, false, true> : kmain;
-                const int lane_tiles = main2_blocks * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
-                // seed launch A
-                gact::ChainQueues qa = queues(ln, sl);
-                qa.list = sl.order.p; qa.list_n = nA;
-                hipLaunchKernelGGL(kseed, dim3(seed_blocks_for(nA, e->seed_lin_grid_blocks)), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc,
-                                   d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file, sl.overlaps.p, qa, ln.d_ws);
-                HIP_TRY(hipGetLastError());
-                if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, ln.stream));
-                HIP_TRY(hipEventRecord(sl.aux_ev_a, ln.stream));
-                // aux stream: seed launch B into the second set, the flag, main launch 2
-                HIP_TRY(hipStreamWaitEvent(sl.aux_stream, sl.aux_ev_a, 0));
-                gact::ChainQueues qb = second_queues(ln, sl);
-                qb.list = sl.order.p + nA; qb.list_n = count - nA;
-                if (count > nA) {
-                    hipLaunchKernelGGL(kseed, dim3(seed_blocks_for(count - nA, main2_blocks)), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp,
-                                       e->kc, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file, sl.overlaps.p, qb, ln.d_ws + ws_split);
-                    HIP_TRY(hipGetLastError());
-                }
-                HIP_TRY(hipMemsetAsync(ln.d_counter + 7, 0xff, sizeof(int), sl.aux_stream));
-                // (both main launches take set 1 -- the longer chains, complete since seed launch A ended -- and then set 2,
-                //  open by the time main launch 2 starts)
-                gact::ChainQueues q2 = queues(ln, sl);
-                {
-                    const gact::ChainQueues s2 = second_queues(ln, sl);
-                    q2.more_flag = ln.d_counter + 7;
-                    q2.more_count = s2.bucket_count; q2.more_pop = s2.bucket_pop; q2.more_live = s2.live;
-                }
-                if (count > nA) {
-                    if (roles)
-                        hipLaunchKernelGGL(kmain_roles, dim3(role2_blocks), dim3(gact::kRoleThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
-                                           same_file, sl.overlaps.p, q2, ln.d_ws + ws_split);
-                    else
-                        hipLaunchKernelGGL(kmain2, dim3(main2_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp, e->kc, d_rs, d_qf, d_qr,
-                                           same_file, sl.overlaps.p, q2, ln.d_ws + ws_split);
-                    HIP_TRY(hipGetLastError());
-                }
-                HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
-                // main launch 1: set 1, then set 2
-                gact::ChainQueues q1 = q2;
-                if (lane && count > nA) q1.leave_longest = lane_tiles;
-                if (roles)
-                    hipLaunchKernelGGL(kmain_roles, dim3(role1_blocks), dim3(gact::kRoleThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr,
-                                       same_file, sl.overlaps.p, q1, ln.d_ws);
-                else
-                    hipLaunchKernelGGL(kmain, dim3(main1_blocks), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr,
-                                       same_file, sl.overlaps.p, q1, ln.d_ws);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
-                if (first_pass) { sl.wide = false; sl.lin = true; sl.lane = lane && count > nA; sl.roles = roles; }
-                sl.overlapped = true;
-                return 0;
+        if (plan.seq == pol::Seq::Overlapped) {
+            if ((rc = ensure_aux_stream(sl))) return rc;
+            const int ob = std::max(1, std::min((count + 255) / 256, 1024));
+            hipLaunchKernelGGL(gact::order_hist_kernel, dim3(ob), dim3(256), 0, ln.stream, sl.cands.p, first, count, rc_from, d_rs.offsets,
+                               d_qf.offsets, d_qr.offsets, kp.early, ln.d_counter + kOrderHist);
+            hipLaunchKernelGGL(gact::order_scatter_kernel, dim3(ob), dim3(256), 0, ln.stream, sl.cands.p, first, count, rc_from,
+                               d_rs.offsets, d_qf.offsets, d_qr.offsets, kp.early, ln.d_counter + kOrderHist,
+                               ln.d_counter + kOrderCursor, sl.order.p);
+            HIP_TRY(hipGetLastError());
+            const int nA = plan.nA;
+            // seed launch A
+            gact::ChainQueues qa = queues(ln, sl);
+            qa.list = sl.order.p; qa.list_n = nA;
+            if ((rc = launch_seed(plan.seed, plan.seed_blocks, ln.stream, qa, ln.d_ws))) return rc;
+            if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, ln.stream));
+            HIP_TRY(hipEventRecord(sl.aux_ev_a, ln.stream));
+            // aux stream: seed launch B into the second set, the flag, main launch 2
+            HIP_TRY(hipStreamWaitEvent(sl.aux_stream, sl.aux_ev_a, 0));
+            gact::ChainQueues qb = second_queues(ln, sl);
+            qb.list = sl.order.p + nA; qb.list_n = count - nA;
+            if (count > nA && (rc = launch_seed(plan.seed, plan.seedB_blocks, sl.aux_stream, qb, ln.d_ws + plan.ws_split))) return rc;
+            HIP_TRY(hipMemsetAsync(ln.d_counter + 7, 0xff, sizeof(int), sl.aux_stream));
+            // (both main launches take set 1 -- the longer chains, complete since seed launch A ended -- and then set 2,
+            //  open by the time main launch 2 starts)
+            gact::ChainQueues q2 = queues(ln, sl);
+            {
+                const gact::ChainQueues s2 = second_queues(ln, sl);
+                q2.more_flag = ln.d_counter + 7;
+                q2.more_count = s2.bucket_count; q2.more_pop = s2.bucket_pop; q2.more_live = s2.live;
             }
+            // (the critical lane, ChainQueues::leave_longest: main launch 2 in the wide layout, main launch 1 leaves it that many
+            //  of the longest chains -- GACT_HIP_CRIT_LANE_ALWAYS; a run this size is bound by throughput)
+            if (count > nA && (rc = launch_main(plan.lane ? pol::MainK::WideLin : plan.main, true, plan.main2_blocks, sl.aux_stream, q2, ln.d_ws + plan.ws_split))) return rc;
+            HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
+            // main launch 1: set 1, then set 2
+            gact::ChainQueues q1 = q2;
+            q1.leave_longest = plan.leave_longest;
+            if ((rc = launch_main(plan.main, true, plan.main_blocks, ln.stream, q1, ln.d_ws))) return rc;
+            HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
+            if (first_pass) { sl.wide = false; sl.lin = true; sl.lane = plan.lane; sl.roles = plan.roles; }
+            sl.overlapped = true;
+            return 0;
         }
-        // the packed kernels exist twice: for sets compared as raw bytes and for 2-bit sets (LUT substitution score)
-        if (e->seed16) {
-            int blocks16 = grid((groups_needed + 3) / 4, e->seed_grid_blocks);
-            auto k16 = raw ? gact::seed_p16_kernel<C, true> : gact::seed_p16_kernel<C, false>;
-            if constexpr (C == 20) {                     // the drifted seed passes exist for the 20-column geometry only
-                if (!raw && e->lin) {
-                    k16 = gact::seed_p16_kernel<C, false, 1>;
-                    blocks16 = grid((groups_needed + 3) / 4, e->seed_lin_grid_blocks);
-                } else if (!raw && e->aff && e->aff_seed) {
-                    k16 = e->params.mismatch < e->params.gap_extend ? gact::seed_p16_kernel<C, false, 3> : gact::seed_p16_kernel<C, false, 2>;
-                }
-            }
-            hipLaunchKernelGGL(k16, dim3(blocks16), dim3(gact::kBlockThreads), 0, ln.stream,
-                               kp, e->kc, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from,
-                               same_file, sl.overlaps.p, cq, ln.d_ws);
-        } else {
-            hipLaunchKernelGGL((gact::extend_kernel<C>), dim3(seed_blocks), dim3(gact::kBlockThreads), 0, ln.stream,
-                               kp, d_rs, d_qf, d_qr, sl.cands.p, first, n, rc_from, same_file,
-                               sl.overlaps.p, cq, e->p16 ? 1 : 0, ln.d_ws);
-        }
-        HIP_TRY(hipGetLastError());
-        { int trc = traced(ln, raw ? "seed launch (raw bytes)" : "seed launch (2-bit)", seed_blocks, count); if (trc) return trc; }
-        if (!e->p16) return 0;
+        // ---- seed launch, then the main launch(es)
+        if ((rc = launch_seed(plan.seed, plan.seed_blocks, ln.stream, cq, ln.d_ws))) return rc;
+        if ((rc = traced(ln, raw ? "seed launch (raw bytes)" : "seed launch (2-bit)", plan.seed_blocks, count))) return rc;
+        if (plan.seq == pol::Seq::SingleInt32) return 0;
         if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, ln.stream));
-        { int prc = poison_lane(e, ln, 0x5bd1e995u); if (prc) return prc; }      // the main launch reads nothing the seed launch stored
-        // fewer chains than the narrow layouts have tile slots: the launch lasts as long as its longest chain, so
-        // chains are made faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous
-        const int narrow_slots = e->grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
-        // (the side lane's few chains are latency-bound whatever else runs)
-        // (a run of fewer chains than tile slots but several per slot of the critical lane: the lane for its longest chains, one
-        //  wide wave per SIMD, and the split launch beside it for the rest -- GACT_HIP_LANE_SMALL, see the lane below)
-        const int lane_tiles_small = (e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3) * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
-        const bool lane_small = C == 20 && e->lane_small && e->crit_lane && e->wide == 0 && e->lin && e->split && !raw && !trace && !second_set &&
-                                !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 && count <= narrow_slots &&
-                                count >= e->lane_small_factor * lane_tiles_small / 2 && e->lin_grid_blocks >= 3;
-        const bool wide = C == 20 && e->wide >= 0 && !lane_small && (e->wide > 0 || (count <= narrow_slots && (!shared_machine || ln.stream != sl.stream)));
-        using gact::extend_p16_kernel;
-        const bool tg = e->tagged;
-        const bool lin = e->lin && !raw && (wide || e->split);
-        const bool aff = e->aff && !raw && !wide && C == 20;
-        // the split linear-gap launch with DP waves and walker waves (gact_roles.hpp)
-        const bool roles = C == 20 && e->roles && lin && !wide && !(shared_machine && ln.stream == sl.stream && e->team_when_shared);
-        if (first_pass) { sl.wide = wide; sl.lin = lin; sl.aff = aff; sl.roles = roles; }
-        auto km = lin ? (wide ? extend_p16_kernel<gact::WideLayoutLin, false>
-                              : (shared_machine && ln.stream == sl.stream && e->team_when_shared)
-                                    ? extend_p16_kernel<gact::SplitLayoutLinTeam<7, 13>, false>
-                                    : extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>)
-                : aff ? (e->params.mismatch < e->params.gap_extend ? extend_p16_kernel<gact::SplitLayoutAff<7, 13, true>, false>
-                                                                   : extend_p16_kernel<gact::SplitLayoutAff<7, 13, false>, false>)
-                : wide ? (tg ? (raw ? extend_p16_kernel<gact::WideLayoutTagged, true> : extend_p16_kernel<gact::WideLayoutTagged, false>)
-                             : (raw ? extend_p16_kernel<gact::WideLayout, true> : extend_p16_kernel<gact::WideLayout, false>))
-                : e->split ? (tg ? (raw ? extend_p16_kernel<gact::SplitLayout<7, 13, true>, true>
-                                        : extend_p16_kernel<gact::SplitLayout<7, 13, true>, false>)
-                                 : (raw ? extend_p16_kernel<gact::SplitLayout<7, 13>, true>
-                                        : extend_p16_kernel<gact::SplitLayout<7, 13>, false>))
-                           : (tg ? (raw ? extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, true>
-                                        : extend_p16_kernel<gact::UniformLayout<C, gact::kGroup, true>, false>)
-                                 : (raw ? extend_p16_kernel<gact::UniformLayout<C>, true>
-                                        : extend_p16_kernel<gact::UniformLayout<C>, false>));
-        // two waves per SIMD, not three: this launch lasts as long as its longest chain, and a wave advances a chain
-        // at one instruction per ~11 cycles with one neighbour on its SIMD, ~15 with two (8 alone, but then half the
-        // VALU idles): ONT-shape workload 150 ms -> 116 ms; one wave per SIMD: 132 ms
-        // (round 4, the linear-gap wide launch: with more chains than TWO blocks per CU hold tile slots the launch is bound by
-        //  throughput either way, and two wide waves on a SIMD get little more through than one -- 0.19 ms an iteration each
-        //  against 0.108 -- while every chain advances that much slower: ONT shape alone 81.5-83.8 ms at two blocks per CU,
-        //  77.6-78.8 at one, 112 at three, profiles/r04/ont_wide_blocks_per_cu.txt.  Up to one block per CU of chains the grid
-        //  is that small anyway; in between -- every chain resident at two blocks -- two it stays.)
-        const int slots_at_two = 2 * e->prop.multiProcessorCount * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
-        const int per_cu = e->wide_blocks_per_cu > 0 ? e->wide_blocks_per_cu : (lin && count > slots_at_two) ? 1 : 2;
-        const int wide_cap = std::min(lin ? e->wide_lin_grid_blocks : e->grid_blocks, per_cu * e->prop.multiProcessorCount);
-        const int wide_blocks = grid((count + 15) / 16, wide_cap);             // 4 tiles per wave
-        // two waves per SIMD already saturate the DP code (DESIGN 5.0 "Resident waves"): a launch that shares the machine
-        // takes two blocks per CU of the three that fit -- the next launch's blocks get in sooner, a third less workspace is live
-        const int lin_cap = (shared_machine && ln.stream == sl.stream) ? std::max(1, e->lin_grid_blocks * 2 / 3) : e->lin_grid_blocks;
-        const int lin_blocks = grid((groups_needed + 3) / 4, lin_cap);
-        const int aff_cap = e->aff_grid_blocks;
-        const int main_blocks_now = aff ? grid((groups_needed + 3) / 4, aff_cap) : main_blocks;
-        if constexpr (C == 20) {
+        if ((rc = poison_lane(e, ln, 0x5bd1e995u))) return rc;      // the main launch reads nothing the seed launch stored
+        if (first_pass) { sl.wide = plan.wide; sl.lin = plan.lin; sl.aff = plan.aff; sl.roles = plan.roles; }
+        if (plan.seq == pol::Seq::CritLane) {
             // The critical lane beside a run's ONE split main launch (a run too small for overlapped seeding, e.g. the merged
             // forward-strand calls of eight feeder threads: 33 k chains on 24.6 k tile slots last as long as their longest
             // chain): the wide launch on a third of the blocks, on the second stream, behind the seed launch like the split one
-            const int narrow_slots0 = e->lin_grid_blocks * (gact::kBlockThreads / 64) * gact::kGroupsPerWave * gact::kSlots;
-            // (GACT_HIP_LANE_BLOCKS=<n>: another size for the lane, the split launch takes the rest)
-            const int lane_blocks = e->lane_blocks > 0 ? std::min(e->lane_blocks, e->lin_grid_blocks / 2) : e->lin_grid_blocks - e->lin_grid_blocks * 2 / 3;
-            if (!roles && e->crit_lane && e->wide == 0 && lin && !wide && !raw && !trace && !second_set && !shared_machine && ln.stream == sl.stream && ln.max_blocks == 0 &&
-                !e->team_when_shared && (count > narrow_slots || lane_small) && (count < narrow_slots0 + narrow_slots0 / 2 || e->crit_lane_always) &&
-                count <= 4 * narrow_slots0 && e->lin_grid_blocks >= 3 &&
-                lane_blocks <= e->wide_lin_grid_blocks) {
-                { int arc = ensure_aux_stream(sl); if (arc) return arc; }
-                const int split_blocks = grid((groups_needed + 3) / 4, e->lin_grid_blocks - lane_blocks);
-                const size_t ws_split = ws_words_for(e, e->lin_grid_blocks - lane_blocks);
-                HIP_TRY(hipEventRecord(sl.aux_ev_a, ln.stream));
-                HIP_TRY(hipStreamWaitEvent(sl.aux_stream, sl.aux_ev_a, 0));
-                hipLaunchKernelGGL((extend_p16_kernel<gact::WideLayoutLin, false>), dim3(lane_blocks), dim3(gact::kBlockThreads), 0, sl.aux_stream, kp,
-                                   e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws + ws_split);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
-                gact::ChainQueues cq1 = cq;
-                cq1.leave_longest = lane_blocks * (gact::kBlockThreads / 64) * 2 * gact::kSlots;
-                hipLaunchKernelGGL(km, dim3(split_blocks), dim3(gact::kBlockThreads), 0, ln.stream, kp, e->kc, d_rs, d_qf, d_qr, same_file,
-                                   sl.overlaps.p, cq1, ln.d_ws);
-                HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
-                if (first_pass) sl.lane = true;
-                return 0;
-            }
+            if ((rc = ensure_aux_stream(sl))) return rc;
+            HIP_TRY(hipEventRecord(sl.aux_ev_a, ln.stream));
+            HIP_TRY(hipStreamWaitEvent(sl.aux_stream, sl.aux_ev_a, 0));
+            if ((rc = launch_main(pol::MainK::WideLin, false, plan.main2_blocks, sl.aux_stream, cq, ln.d_ws + plan.ws_split))) return rc;
+            HIP_TRY(hipEventRecord(sl.aux_ev_b, sl.aux_stream));
+            gact::ChainQueues cq1 = cq;
+            cq1.leave_longest = plan.leave_longest;
+            if ((rc = launch_main(plan.main, false, plan.main_blocks, ln.stream, cq1, ln.d_ws))) return rc;
+            HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
+            if (first_pass) sl.lane = true;
+            return 0;
         }
-        if constexpr (C == 20) {
-            if (roles) {
-                // a block holds kRoleDp waves x 4 groups x 2 tiles x 2 banks; with fewer chains than that the blocks are spread
-                // over the machine one bank full each before the second banks fill
-                const int per_bank = gact::kRoleDp * gact::kGroupsPerWave * gact::kSlots;
-                const int role_blocks = grid((count + per_bank - 1) / per_bank, e->role_grid_blocks);
-                hipLaunchKernelGGL((gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(role_blocks), dim3(gact::kRoleThreads), 0,
-                                   ln.stream, kp, e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws);
-                HIP_TRY(hipGetLastError());
-                return traced(ln, "main launch (2-bit, DP + walker waves)", role_blocks, count);
-            }
-        }
-        hipLaunchKernelGGL(km, dim3(wide ? wide_blocks : (lin ? lin_blocks : main_blocks_now)), dim3(gact::kBlockThreads), 0, ln.stream, kp,
-                           e->kc, d_rs, d_qf, d_qr, same_file, sl.overlaps.p, cq, ln.d_ws);
-        HIP_TRY(hipGetLastError());
-        return traced(ln, raw ? "main launch (raw bytes)" : "main launch (2-bit)", wide ? wide_blocks : (lin ? lin_blocks : main_blocks_now), count);
+        if ((rc = launch_main(plan.main, false, plan.main_blocks, ln.stream, cq, ln.d_ws))) return rc;
+        return traced(ln, raw ? "main launch (raw bytes)" : "main launch (2-bit)", plan.main_blocks, count);
     };
 
     const Lane own = main_lane(e, sl);
@@ -1161,40 +1099,11 @@ extern "C" {
 
 const char *gact_hip_last_error(void) { return g_err.c_str(); }
 
-int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
+// what the parameters and the switches allow: geometry, kernel families, scheduling flags (no HIP call: gact_hip_create and
+// gact_hip_plan_describe share it).  Returns whether the tile size belongs to gact_big.hpp.
+static bool derive_kernel_flags(gact_hip_engine *e)
 {
-    if (!p || !out) return fail(GACT_HIP_EINVAL, "create: NULL argument");
-    *out = nullptr;
-    if (p->tile_size < 1 || p->tile_size > GACT_HIP_MAX_TILE)
-        return fail(GACT_HIP_EINVAL, "tile_size %d not in [1,%d]", p->tile_size, GACT_HIP_MAX_TILE);
-    if (p->tile_overlap < 0 || p->tile_overlap >= p->tile_size)
-        return fail(GACT_HIP_EINVAL, "tile_overlap %d must be in [0, tile_size)", p->tile_overlap);
-    if (p->mismatch > 0 || p->gap_open > 0 || p->gap_extend > 0)
-        return fail(GACT_HIP_EINVAL, "scoring: mismatch, gap_open and gap_extend must be <= 0");
-    if (p->match < 0 || (int64_t)p->match * p->tile_size > (1 << 28) ||
-        p->mismatch < -(1 << 20) || p->gap_open < -(1 << 20) || p->gap_extend < -(1 << 20))
-        return fail(GACT_HIP_EINVAL, "scoring: values out of the int32-safe range");
-    if (p->first_tile_score_threshold < 1)
-        return fail(GACT_HIP_EINVAL, "first_tile_score_threshold must be >= 1 (the reference loops forever otherwise, gact.cpp:82)");
-    if (p->n_slots < 1 || p->n_slots > 256) return fail(GACT_HIP_EINVAL, "n_slots %d not in [1,256]", p->n_slots);
-
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-        return fail(GACT_HIP_EDEVICE, "no HIP device visible: this engine has no CPU fallback");
-    if (p->device_id < 0 || p->device_id >= ndev)
-        return fail(GACT_HIP_EINVAL, "device_id %d not in [0,%d)", p->device_id, ndev);
-
-#ifdef GACT_EXPERIMENTS
-    fprintf(stderr, "[gact_hip] built with -DGACT_EXPERIMENTS: timing experiments may be compiled in, results are NOT to be trusted\n");
-#endif
-    gact_hip_engine *e = new gact_hip_engine();
-    e->params = *p;
-    int rc = set_device(e);
-    if (rc) { delete e; return rc; }
-    if (hipGetDeviceProperties(&e->prop, p->device_id) != hipSuccess) {
-        delete e;
-        return fail(GACT_HIP_EDEVICE, "hipGetDeviceProperties failed");
-    }
+    const gact_hip_params *p = &e->params;
     e->C = (p->tile_size <= 20 * gact::kGroup) ? 20 : 32;
     const bool big = p->tile_size > 32 * gact::kGroup;               // gact_big.hpp
     if (big) e->big_cb = p->tile_size <= gact::BigGeom<16>::kTileMax ? 16 : 32;
@@ -1233,6 +1142,44 @@ int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
     if (const char *v = opt_env("poison_ws")) e->poison = (uint32_t)strtoul(v, nullptr, 0) | 0x80000000u;
     e->wide = opt_env("force_wide") ? 1 : opt_env("no_wide") ? -1 : 0;
     if (const char *v = opt_env("wide_blocks_per_cu")) e->wide_blocks_per_cu = atoi(v);
+    return big;
+}
+
+int gact_hip_create(const gact_hip_params *p, gact_hip_engine **out)
+{
+    if (!p || !out) return fail(GACT_HIP_EINVAL, "create: NULL argument");
+    *out = nullptr;
+    if (p->tile_size < 1 || p->tile_size > GACT_HIP_MAX_TILE)
+        return fail(GACT_HIP_EINVAL, "tile_size %d not in [1,%d]", p->tile_size, GACT_HIP_MAX_TILE);
+    if (p->tile_overlap < 0 || p->tile_overlap >= p->tile_size)
+        return fail(GACT_HIP_EINVAL, "tile_overlap %d must be in [0, tile_size)", p->tile_overlap);
+    if (p->mismatch > 0 || p->gap_open > 0 || p->gap_extend > 0)
+        return fail(GACT_HIP_EINVAL, "scoring: mismatch, gap_open and gap_extend must be <= 0");
+    if (p->match < 0 || (int64_t)p->match * p->tile_size > (1 << 28) ||
+        p->mismatch < -(1 << 20) || p->gap_open < -(1 << 20) || p->gap_extend < -(1 << 20))
+        return fail(GACT_HIP_EINVAL, "scoring: values out of the int32-safe range");
+    if (p->first_tile_score_threshold < 1)
+        return fail(GACT_HIP_EINVAL, "first_tile_score_threshold must be >= 1 (the reference loops forever otherwise, gact.cpp:82)");
+    if (p->n_slots < 1 || p->n_slots > 256) return fail(GACT_HIP_EINVAL, "n_slots %d not in [1,256]", p->n_slots);
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GACT_HIP_EDEVICE, "no HIP device visible: this engine has no CPU fallback");
+    if (p->device_id < 0 || p->device_id >= ndev)
+        return fail(GACT_HIP_EINVAL, "device_id %d not in [0,%d)", p->device_id, ndev);
+
+#ifdef GACT_EXPERIMENTS
+    fprintf(stderr, "[gact_hip] built with -DGACT_EXPERIMENTS: timing experiments may be compiled in, results are NOT to be trusted\n");
+#endif
+    gact_hip_engine *e = new gact_hip_engine();
+    e->params = *p;
+    int rc = set_device(e);
+    if (rc) { delete e; return rc; }
+    if (hipGetDeviceProperties(&e->prop, p->device_id) != hipSuccess) {
+        delete e;
+        return fail(GACT_HIP_EDEVICE, "hipGetDeviceProperties failed");
+    }
+    const bool big = derive_kernel_flags(e);
     e->kp.prio_bases[0] = e->kp.prio_bases[1] = 0x7fffffff;
     // pointer words of the linear-gap main launch are stored within `band` columns of the diagonal through a tile's (R, Q);
     // a walk that comes within a refill of its edge has its tile run again with the whole window (exact either way).
@@ -2202,6 +2149,37 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
         return fail(GACT_HIP_EINVAL, "set_option: unknown option '%s'", name);
     }
     return 0;
+}
+
+// The launch plan (gact_policy.hpp) an engine of these parameters makes for a pass of `count` candidates, on a machine of
+// `compute_units` CUs at the kernels' nominal occupancies (three blocks of four waves per CU for the main and the linear-gap
+// seed launches, two for the other seed launches, one role block): no engine, no device.  flags: bit 0 the sets hold bytes
+// other than A/C/G/T (raw-byte kernels), bit 1 the launch shares the machine, bit 2 the role launch is switched on.
+int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, int32_t count, int32_t flags, char *buf, int64_t cap)
+{
+    if (!p || compute_units < 1 || count < 0) return fail(GACT_HIP_EINVAL, "plan_describe: bad arguments");
+    gact_hip_engine e;
+    e.params = *p;
+    const bool big = derive_kernel_flags(&e);
+    std::string t;
+    if (big) t = "{\"sequence\": \"one wave per tile (gact_big.hpp)\"}";
+    else {
+        e.prop.multiProcessorCount = compute_units;
+        e.kp.ws_words = (e.C == 20) ? gact::Geometry<20>::kWsWords : gact::Geometry<32>::kWsWords;
+        e.grid_blocks = e.lin_grid_blocks = e.wide_lin_grid_blocks = e.aff_grid_blocks = e.seed_lin_grid_blocks = 3 * compute_units;
+        e.seed_grid_blocks = 2 * compute_units;
+        e.role_grid_blocks = (e.lin && e.split && e.C == 20) ? compute_units : 0;
+        if (flags & 4) e.roles = e.role_grid_blocks > 0;
+        gact_policy::Inputs in;
+        in.count = count; in.raw = (flags & 1) != 0; in.shared_machine = (flags & 2) != 0;
+        t = gact_policy::describe(gact_policy::plan_pass(policy_caps(&e), in));
+    }
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>((size_t)cap - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)t.size() + 1;
 }
 
 int64_t gact_hip_options_describe(char *buf, int64_t cap)

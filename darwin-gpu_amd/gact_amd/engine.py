@@ -14,7 +14,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
            ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp", "gact_lin.hpp",
-            "gact_aff.hpp", "gact_roles.hpp", "gact_big.hpp", "gact_gather.hpp", "dsoft_device.hpp", "dsoft_engine.hpp")] + \
+            "gact_aff.hpp", "gact_roles.hpp", "gact_policy.hpp", "gact_big.hpp", "gact_gather.hpp", "dsoft_device.hpp", "dsoft_engine.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
 SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2
@@ -210,7 +210,21 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_measure_valu_rate", "gact_hip_format_overlap", "gact_hip_dsoft_build", "gact_hip_dsoft_query",
            "gact_hip_candidates_download", "gact_hip_derive_revcomp", "gact_hip_register_output",
            "gact_hip_unregister_output", "gact_hip_set_option", "gact_hip_prepare",
-           "gact_hip_comm_create", "gact_hip_comm_gather_lines", "gact_hip_comm_destroy", "gact_hip_options_describe")
+           "gact_hip_comm_create", "gact_hip_comm_gather_lines", "gact_hip_comm_destroy", "gact_hip_options_describe", "gact_hip_plan_describe")
+
+
+def plan(count, flags=0, compute_units=256, tile_size=320, tile_overlap=120, scoring=(1, -1, -1, -1), threshold=35):
+    """the launch plan of gact_policy.hpp for one pass over `count` candidates (no device needed); flags: 1 raw bytes,
+    2 the launch shares the machine, 4 role launch on"""
+    import json
+    lib = load()
+    lib.gact_hip_plan_describe.restype = C.c_int64
+    lib.gact_hip_plan_describe.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_int64]
+    p = Params(tile_size, tile_overlap, scoring[0], scoring[1], scoring[2], scoring[3], threshold, 0, 1, 0)
+    buf = C.create_string_buffer(1024)
+    if lib.gact_hip_plan_describe(C.byref(p), compute_units, count, flags, buf, 1024) < 0:
+        raise GactHipError(lib.gact_hip_last_error().decode())
+    return json.loads(buf.value.decode())
 
 
 def options_table():

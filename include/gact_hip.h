@@ -316,6 +316,12 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value);
  * class | what it does`.  Writes at most cap bytes (NUL-terminated) into buf, returns the size the whole table needs.
  * No engine, no device. */
 int64_t gact_hip_options_describe(char *buf, int64_t cap);
+/* The launch plan -- sequence, kernels, grids -- that an engine of parameters p makes for one pass over `count` candidates on a
+ * device of compute_units CUs (kernels at their nominal occupancy), as one JSON object.  flags: bit 0 = the read sets hold
+ * bytes other than A/C/G/T, bit 1 = the launch shares the machine (other runs in flight), bit 2 = role launch on.
+ * The policy is a pure function (csrc/gact_policy.hpp); this entry exists so that it can be swept and tested without a
+ * device.  Same buffer convention as gact_hip_options_describe. */
+int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, int32_t count, int32_t flags, char *buf, int64_t cap);
 
 /* device address of the slot's gact_overlap array (for an RCCL gather) */
 void *gact_hip_device_overlaps(gact_hip_engine *e, int slot);

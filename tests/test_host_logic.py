@@ -48,3 +48,75 @@ def test_length_classes_and_kernel_predicates(tmp_path):
     assert out[4] == "tile512 1 1"
     assert out[5] == "pk2 ffffffff 00030003"
     assert out[6] == "lin 1 0 0 1 0 1"
+
+
+# ---- the launch policy (csrc/gact_policy.hpp through gact_hip_plan_describe: no device) --------------------------------
+def _plan(count, **kw):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "darwin-gpu_amd"))
+    from gact_amd import engine
+    return engine.plan(count, **kw)
+
+
+def test_launch_policy_operating_points():
+    """the four sequences of a pass, at the thresholds DESIGN 3.5 names (S = 24,576 resident tile slots on 256 CUs)"""
+    S = 3 * 256 * 32
+    for n, seq, main in ((1, "seed+main", "WideLayoutLin"), (S, "seed+main", "WideLayoutLin"),
+                         (S + 1, "seed+main+critical-lane", "SplitLayoutLin"), (S + S // 2 - 1, "seed+main+critical-lane", "SplitLayoutLin"),
+                         (S + S // 2, "overlapped-seeding", "SplitLayoutLin"), (4 * S, "overlapped-seeding", "SplitLayoutLin"),
+                         (4 * S + 1, "seed+main", "SplitLayoutLin"), (3_000_000, "seed+main", "SplitLayoutLin")):
+        p = _plan(n)
+        assert (p["sequence"], p["main_kernel"]) == (seq, main), (n, p)
+        assert p["seed_kernel"] == "seed_p16<lin>" and p["linear"] and not p["roles"]
+    # a launch that shares the machine: the throughput layout on two thirds of the blocks, no second stream, whatever the count
+    for n in (100, S, 2 * S, 10 * S):
+        p = _plan(n, flags=2)
+        assert p["sequence"] == "seed+main" and p["main_kernel"] == "SplitLayoutLin" and p["main_blocks"] <= 512, (n, p)
+    # the role launch: one block of twelve waves per CU, in the same sequences
+    p = _plan(2 * S, flags=4)
+    assert p["main_kernel"] == "roles<SplitLayoutLin>" and p["main_blocks"] + p["second_main_blocks"] == 256 and p["roles"]
+    assert _plan(10 * S, flags=4)["main_blocks"] == 256 and _plan(10 * S, flags=4)["sequence"] == "seed+main"
+    # other scorings and raw-byte sets: the drifted affine pass / the tagged raw kernels, never the linear-gap sequences
+    p = _plan(2 * S, scoring=(2, -3, -5, -2))
+    assert p["sequence"] == "seed+main" and p["main_kernel"] == "SplitLayoutAff<cbneg>" and p["affine_drift"]
+    assert _plan(2 * S, scoring=(3, -2, -4, -2))["main_kernel"] == "SplitLayoutAff"
+    assert _plan(2 * S, flags=1)["main_kernel"] == "SplitLayout<tag,raw>" and _plan(2 * S, flags=1)["seed_kernel"] == "seed_p16<raw>"
+    assert _plan(2 * S, scoring=(100, -90, -200, -50))["sequence"] == "int32-one-launch"
+    assert _plan(2 * S, tile_size=512, tile_overlap=128)["main_kernel"].startswith("UniformLayout")
+    assert "gact_big" in _plan(10, tile_size=1024, tile_overlap=256)["sequence"]
+
+
+def test_launch_policy_is_sane_over_a_sweep_of_counts():
+    """1 ... 3 M candidates: grids never exceed the machine, never shrink as the list grows inside one sequence, every
+    candidate of a list up to the resident tile slots has a slot of its own, and the two launches of a split sequence
+    share the workspace without overlap"""
+    import math
+    S, cus = 3 * 256 * 32, 256
+    ws_total = 3 * cus * 32 * 13760                     # words: what gact_hip_create allocates per slot for these grids
+    prev = None
+    n = 1
+    while n <= 3_000_000:
+        for flags in (0, 2, 4):
+            p = _plan(n, flags=flags)
+            assert 1 <= p["seed_blocks"] <= 3 * cus and 1 <= p["main_blocks"] <= 3 * cus and p["second_main_blocks"] <= cus
+            per_block = 16 if p["wide"] else 160 if p["roles"] else 32
+            slots = (p["main_blocks"] + (p["second_main_blocks"] if not p["critical_lane"] else 0)) * per_block
+            if p["critical_lane"]:
+                slots += p["second_main_blocks"] * 16
+            # (a role block spreads one bank's worth per block first; the wide launch deliberately takes ONE block per CU once
+            #  it has more chains than two blocks per CU hold: bound by throughput either way, DESIGN 5.00)
+            #  ... and a launch that shares the machine two blocks per CU of the three)
+            if not p["wide"]:
+                #  (the critical lane's third of the blocks holds 16 tiles a block, not 32)
+                floor_slots = cus * 80 if p["roles"] else S * 2 // 3 if flags == 2 else S * 5 // 6 if p["critical_lane"] else S
+                assert slots >= min(n, floor_slots), (n, flags, p)
+            if p["sequence"] in ("overlapped-seeding", "seed+main+critical-lane"):
+                second = p["second_main_blocks"] * (16 if p["critical_lane"] else per_block) * 13760
+                assert 0 < p["ws_split_words"] and (p["roles"] or p["ws_split_words"] + second <= ws_total), (n, p)
+            if p["sequence"] == "overlapped-seeding":
+                assert 0 < p["n_a"] <= n and p["seed_b_blocks"] >= 1
+        q = _plan(n)
+        if prev is not None and prev["sequence"] == q["sequence"] and prev["main_kernel"] == q["main_kernel"] and not q["wide"]:
+            assert q["main_blocks"] >= prev["main_blocks"], (n, prev, q)
+        prev = q
+        n = int(math.ceil(n * 1.37))

@@ -231,6 +231,12 @@ def main():
     ap.add_argument("--no-reference-caller", action="store_true",
                     help="skip the reference's own unmodified darwin.cpp on the engine (a child process behind the timed region, N = 1)")
     ap.add_argument("--no-cabi-gather-check", action="store_true", help="N > 1: skip the second gather through the C-ABI's own RCCL path")
+    ap.add_argument("--strong-blocks-of", default="pacbio50mb",
+                    help="the genome blocks the fixed strong-scaling job is made of (tests: a small one; config 4 is pacbio50mb)")
+    ap.add_argument("--rehearse-on-one-device", action="store_true",
+                    help="the whole N > 1 path -- block exchange, deal, steps in flight, gather, checksums -- with every rank on device 0 "
+                         "and the collectives over gloo on host tensors (RCCL refuses two ranks on one device): a rehearsal, not a "
+                         "measurement; the line says so")
     args = ap.parse_args()
     if args.workload == "config4":
         args.scaling = "strong"
@@ -255,8 +261,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        global CDEV
+        if args.rehearse_on_one_device:
+            CDEV = "cpu"
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import numpy as np
     from gact_amd import engine, workload
@@ -276,7 +288,7 @@ def main():
     # ---- workload: one genome block per rank, read sets replicated everywhere
     t_gen = time.time()
     blk = workload.make_block(args.workload, block=rank, candidates=args.candidates)
-    blocks = gdist.exchange_blocks(dist, (blk.rs.reads, blk.cf, blk.cr), world, torch=torch, device="cuda" if use_dist else "cpu")
+    blocks = gdist.exchange_blocks(dist, (blk.rs.reads, blk.cf, blk.cr), world, torch=torch, device=CDEV if use_dist else "cpu")
     reads, cf_all, cr_all = gdist.merge_blocks(blocks)
     my_cf = gdist.deal(cf_all, rank, world)
     my_cr = gdist.deal(cr_all, rank, world)
@@ -304,9 +316,9 @@ def main():
         for k in range(S):
             eng.sync(k)
         if use_dist:
-            torch.cuda.synchronize()
+            _sync_cuda(torch)
             dist.barrier()
-            torch.cuda.synchronize()
+            _sync_cuda(torch)
 
     kernel_ms = []
 
@@ -321,7 +333,7 @@ def main():
         # the one collective of the path: gather of fixed-size overlap records to rank 0, straight from
         # the engine's device-resident record array (no host round trip in front of RCCL)
         # (32 bytes per record travel: the eight numbers of an output line; dist.LINE_DTYPE)
-        gather = gdist.RecordGather(torch, dist, nf + nr, gdist.LINE_BYTES, rank, world, "cuda")
+        gather = gdist.RecordGather(torch, dist, nf + nr, gdist.LINE_BYTES, rank, world, CDEV)
         dev_recs = [gdist.DeviceRecords(eng.device_overlaps_ptr(k), nf + nr, engine.OVERLAP_DTYPE.itemsize) for k in range(S)]
 
     ran = set()
@@ -335,7 +347,7 @@ def main():
         gathered = None
         if use_dist:
             eng.sync(slot)                               # the engine's own stream: records complete in HBM
-            parts = gather(dev_recs[slot])
+            parts = gather(dev_recs[slot] if CDEV == "cuda" else gdist.lines_from_overlaps(eng.candidates_fetch(nf + nr, slot=slot)))
             if rank == 0:
                 gathered = gather.to_host(parts, gdist.LINE_DTYPE)          # the job's output, on the host
             rec = None
@@ -386,12 +398,13 @@ def main():
         rec = eng.candidates_fetch(nf + nr, slot=0, out=rec_bufs[0])
         # what rank 0 gathered of EVERY rank is what that rank's engine holds (checksums, one all_gather)
         try:
-            rank_sums = gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
+            rank_sums = gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, CDEV)
         except RuntimeError as err:
             raise SystemExit("bench.py: %s" % err)
         # the same gather once more through the C-ABI's own RCCL path (gact_hip_comm_*, what host/darwin_hip --rccl-gather
         # uses), outside the timed region, compared on rank 0 with what torch.distributed delivered
-        cpp_gather = {"ok": None, "skipped": "--no-cabi-gather-check"} if args.no_cabi_gather_check else \
+        cpp_gather = {"ok": None, "skipped": "--no-cabi-gather-check" if args.no_cabi_gather_check else "gloo rehearsal on one device"} \
+            if (args.no_cabi_gather_check or args.rehearse_on_one_device) else \
             cpp_gather_check(eng, dist, torch, rank, world, nf + nr, gathered)
     for k in sorted(ran - {0}):    # every slot that took a step holds the same records
         if eng.candidates_fetch(nf + nr, slot=k).tobytes() != eng.candidates_fetch(nf + nr, slot=0).tobytes():
@@ -402,10 +415,10 @@ def main():
     my_tiles = int(rf["n_tiles"].sum() + rr["n_tiles"].sum())
     tot_cells, max_dt = my_cells, dt
     if use_dist:
-        v = torch.tensor([float(my_cells), float(my_tiles)], dtype=torch.float64, device="cuda")
+        v = torch.tensor([float(my_cells), float(my_tiles)], dtype=torch.float64, device=CDEV)
         dist.all_reduce(v)
         tot_cells, tot_tiles = int(v[0].item()), int(v[1].item())
-        m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        m = torch.tensor([dt], dtype=torch.float64, device=CDEV)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         max_dt = float(m.item())
     else:
@@ -413,8 +426,8 @@ def main():
 
     gen_all = None
     if use_dist:
-        g = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
-        dist.all_gather(g, torch.tensor([t_gen], dtype=torch.float64, device="cuda"))
+        g = [torch.zeros(1, dtype=torch.float64, device=CDEV) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([t_gen], dtype=torch.float64, device=CDEV))
         gen_all = [round(float(x.item()), 1) for x in g]
     if rank == 0:
         gcups = tot_cells * args.steps / max_dt / 1e9
@@ -554,6 +567,8 @@ def main():
             # what the one RCCL gather delivered: records per rank and each rank's own checksum of what it sent (compared on
             # rank 0 with what arrived, dist.verify_gathered), the seconds every rank took to build its block
             out["config"]["gathered_records"] = int(sum(len(g) for g in gathered))
+            if args.rehearse_on_one_device:
+                out["config"]["rehearsal"] = "every rank on device 0, collectives over gloo on host tensors: the N > 1 code path, not a measurement"
             out["config"]["gather"] = {"ranks": world, "records_per_rank": [int(len(g)) for g in gathered],
                                        "crc32_per_rank": rank_sums if isinstance(rank_sums, list) else None,
                                        "gen_seconds_per_rank": gen_all, "c_abi_rccl_gather": cpp_gather}
@@ -599,11 +614,18 @@ def main():
 
 
 _CPP_GATHER_STUCK = False
+CDEV = "cuda"            # where the collectives' tensors live: "cuda" under nccl (= RCCL), "cpu" under the gloo rehearsal
 
 
-def _config4_build_one(b):
+def _sync_cuda(torch):
+    if CDEV == "cuda":
+        torch.cuda.synchronize()
+
+
+def _config4_build_one(job):
     from gact_amd import workload
-    return workload.config4_blocks([b])[0]
+    b, name = job
+    return workload.config4_blocks([b], name=name)[0]
 
 
 def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, warmup, headline):
@@ -630,15 +652,15 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
         os.environ["LOCAL_WORLD_SIZE"] = "4"
         try:
             with ProcessPoolExecutor(4, mp_context=multiprocessing.get_context("spawn")) as pool:
-                built = dict(pool.map(_config4_build_one, mine))
+                built = dict(pool.map(_config4_build_one, [(b, args.strong_blocks_of) for b in mine]))
         finally:
             if saved is None:
                 os.environ.pop("LOCAL_WORLD_SIZE", None)
             else:
                 os.environ["LOCAL_WORLD_SIZE"] = saved
     else:
-        built = dict(workload.config4_blocks(mine, candidates=args.candidates))
-    blocks = gdist.exchange_block_rounds(dist, built, NB, rank, world, torch=torch, device="cuda" if use_dist else "cpu")
+        built = dict(workload.config4_blocks(mine, candidates=args.candidates, name=args.strong_blocks_of))
+    blocks = gdist.exchange_block_rounds(dist, built, NB, rank, world, torch=torch, device=CDEV if use_dist else "cpu")
     reads, cf_all, cr_all = gdist.merge_blocks(blocks)
     offs = np.zeros(len(reads) + 1, dtype=np.int64)
     offs[1:] = np.cumsum([len(r) for r in reads])
@@ -659,7 +681,7 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
         eng.register_output(bufs[k], slot=k)
     gather = dev_recs = None
     if use_dist:
-        gather = gdist.RecordGather(torch, dist, nf + nr, gdist.LINE_BYTES, rank, world, "cuda")
+        gather = gdist.RecordGather(torch, dist, nf + nr, gdist.LINE_BYTES, rank, world, CDEV)
         dev_recs = [gdist.DeviceRecords(eng.device_overlaps_ptr(k), nf + nr, engine.OVERLAP_DTYPE.itemsize) for k in range(S)]
     gather_s = [0.0]
 
@@ -667,7 +689,7 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
         for k in range(S):
             eng.sync(k)
         if use_dist:
-            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            _sync_cuda(torch); dist.barrier(); _sync_cuda(torch)
 
     def launch(slot):
         eng.candidates_run_mixed(nf + nr, rc_from=nf, same_file=True, slot=slot)
@@ -676,7 +698,7 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
         if use_dist:
             eng.sync(slot)
             tg = time.perf_counter()
-            parts = gather(dev_recs[slot])
+            parts = gather(dev_recs[slot] if CDEV == "cuda" else gdist.lines_from_overlaps(eng.candidates_fetch(nf + nr, slot=slot)))
             out = gather.to_host(parts, gdist.LINE_DTYPE) if rank == 0 else None
             gather_s[0] += time.perf_counter() - tg
             return None, out
@@ -705,7 +727,7 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
     checked = {}
     for g in (0, 5):
         path = os.path.join(ROOT, "tests", "golden", "config_config4_rank%d.npz" % g)
-        if NB % world or g % world != rank or not os.path.exists(path):
+        if NB % world or g % world != rank or not os.path.exists(path) or args.strong_blocks_of != "pacbio50mb":
             continue
         gold = np.load(path)
         stride, first = NB // world, g // world
@@ -721,14 +743,14 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
     tot_cells, tot_tiles, max_dt = my_cells, my_tiles, dt
     per_rank_ms, per_rank_single, gather_ms, all_checked, builds = [my_dt / steps * 1e3], [dt_single * 1e3], None, dict(checked), [round(t_build, 1)]
     if use_dist:
-        v = torch.tensor([float(my_cells), float(my_tiles)], dtype=torch.float64, device="cuda")
+        v = torch.tensor([float(my_cells), float(my_tiles)], dtype=torch.float64, device=CDEV)
         dist.all_reduce(v)
         tot_cells, tot_tiles = int(v[0].item()), int(v[1].item())
-        m = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        m = torch.tensor([dt], dtype=torch.float64, device=CDEV)
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         max_dt = float(m.item())
         row = torch.tensor([my_dt / steps * 1e3, dt_single * 1e3, float(sum(checked.values())), t_build, gather_s[0] / steps * 1e3],
-                           dtype=torch.float64, device="cuda")
+                           dtype=torch.float64, device=CDEV)
         rows = [torch.zeros_like(row) for _ in range(world)]
         dist.all_gather(rows, row)
         rows = [[float(x) for x in r.tolist()] for r in rows]
@@ -737,7 +759,7 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
         gather_ms = round(rows[0][4], 3)
         # what rank 0 gathered of every rank is what that rank's engine holds
         try:
-            gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, "cuda")
+            gdist.verify_gathered(torch, dist, gdist.lines_from_overlaps(rec), gathered, rank, world, CDEV)
         except RuntimeError as err:
             raise SystemExit("bench.py: config 4: %s" % err)
     eng.close()
@@ -745,7 +767,7 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
         return None
     gcups = tot_cells * steps / max_dt / 1e9
     entry = {
-        "workload": "config4_fixed_job (8 pacbio50mb genome blocks, self-overlap)", "scaling": "strong",
+        "workload": "config4_fixed_job (8 %s genome blocks, self-overlap)" % args.strong_blocks_of, "scaling": "strong",
         "value": round(gcups, 2), "unit": "GCUPS", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": round(max_dt / steps * 1e3, 3), "slots_in_flight": S,
         "reads": len(reads), "bases": int(offs[-1]), "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles, "cells_per_step": tot_cells,
@@ -834,7 +856,7 @@ def cpp_gather_check(eng, dist, torch, rank, world, n, gathered):
     th = threading.Thread(target=work, daemon=True)
     th.start()
     th.join(60)
-    stuck = torch.tensor([1.0 if th.is_alive() else 0.0], dtype=torch.float64, device="cuda")
+    stuck = torch.tensor([1.0 if th.is_alive() else 0.0], dtype=torch.float64, device=CDEV)
     dist.all_reduce(stuck, op=dist.ReduceOp.MAX)
     if float(stuck.item()) > 0:
         _CPP_GATHER_STUCK = True

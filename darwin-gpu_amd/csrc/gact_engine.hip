@@ -35,6 +35,7 @@
 #include "gact_lin.hpp"
 #include "gact_aff.hpp"
 #include "gact_roles.hpp"
+#include "gact_coop.hpp"
 #include "gact_policy.hpp"
 #include "gact_big.hpp"
 #include "dsoft_device.hpp"
@@ -124,8 +125,8 @@ template <class T> struct DevBuf {
 struct LaunchStats {
     hipEvent_t ev0 = nullptr, ev_mid = nullptr, ev1 = nullptr, ev_done = nullptr;
     int *h_counter = nullptr;            // pinned: 2 x kCounterInts ints (the lane's own, the side lane's)
-    bool two_phase = false, wide = false, lin = false, aff = false, overlapped = false, lane = false, side_used = false, roles = false;
-    int routed_raw = 0;
+    bool two_phase = false, wide = false, lin = false, aff = false, overlapped = false, lane = false, side_used = false;
+    int routed_raw = 0, roles = 0;
 };
 
 struct Slot {
@@ -151,7 +152,7 @@ struct Slot {
     long merge_prev_gen = -1;            // ... and the one before that (two halves of a group that came apart have it in common)
     bool overlapped = false;             // the last run seeded while its main launch was running
     bool lane = false;                   // ... had a critical lane (a wide main launch beside the split one)
-    bool roles = false;                  // ... ran its main launch(es) with DP waves and walker waves (gact_roles.hpp)
+    int roles = 0;                       // ... ran its main launch(es) with DP waves and walker waves (1, gact_roles.hpp) / cooperative walks (2, gact_coop.hpp)
     // call combiner (Combiner below; all under its mutex)
     std::thread::id last_thread;         // who called last for this slot, and when: is a run from it likely soon?
     std::chrono::steady_clock::time_point last_call{};
@@ -247,6 +248,7 @@ static const OptionDef kOptions[] = {
     {"no_tagged", "GACT_HIP_NO_TAGGED", 'c', 'k', "explicit pointer comparisons instead of tagged scores"},
     {"no_lin", "GACT_HIP_NO_LIN", 'c', 'k', "the affine passes also for linear scorings (gact_lin.hpp off)"},
     {"no_aff", "GACT_HIP_NO_AFF", 'c', 'k', "round 1's tagged affine pass instead of the drifted one (gact_aff.hpp off)"},
+    {"coop", "GACT_HIP_COOP", 'l', 'k', "1: the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback walks (gact_coop.hpp)"},
     {"roles", "GACT_HIP_ROLES", 'l', 'k', "1: the split linear-gap main launch as DP waves + walker waves (gact_roles.hpp; default 0: measured no faster, DESIGN 3.13)"},
     {"no_routing", "GACT_HIP_NO_ROUTING", 'c', 'k', "a set with a non-ACGT byte moves the whole launch onto the raw-byte kernels"},
     {"no_side_lane", "GACT_HIP_NO_SIDE_LANE", 'c', 's', "routed raw-byte launches after the 2-bit ones instead of beside them"},
@@ -358,6 +360,7 @@ struct gact_hip_engine {
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
     bool roles = false;         // GACT_HIP_ROLES=1 / set_option "roles": the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
     int role_grid_blocks = 0;   // ... and its persistent grid (blocks of kRoleThreads)
+    bool coop = false;          // GACT_HIP_COOP=1 / set_option "coop": ... with two banks of tiles per wave and cooperative, batched walks (gact_coop.hpp)
     int aff_grid_blocks = 0;    // ... of the drifted affine split launch (two blocks per CU)
     int wide_lin_grid_blocks = 0;       // ... of the linear-gap wide launch
     gact::P16Consts kc;
@@ -691,7 +694,7 @@ gact_policy::Caps policy_caps(const gact_hip_engine *e)
     gact_policy::Caps c;
     c.C = e->C; c.p16 = e->p16; c.seed16 = e->seed16; c.lin = e->lin; c.aff = e->aff; c.aff_seed = e->aff_seed; c.split = e->split; c.tagged = e->tagged;
     c.mismatch_below_extend = e->params.mismatch < e->params.gap_extend;
-    c.roles = e->roles; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
+    c.roles = e->roles; c.coop = e->coop && e->lin && e->split && e->C == 20; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
     c.lane_small = e->lane_small; c.lane_small_factor = e->lane_small_factor; c.lane_blocks = e->lane_blocks; c.team_when_shared = e->team_when_shared;
     c.wide = e->wide; c.wide_blocks_per_cu = e->wide_blocks_per_cu; c.cus = e->prop.multiProcessorCount;
     c.grid_blocks = e->grid_blocks; c.seed_grid_blocks = e->seed_grid_blocks; c.seed_lin_grid_blocks = e->seed_lin_grid_blocks;
@@ -699,6 +702,7 @@ gact_policy::Caps policy_caps(const gact_hip_engine *e)
     c.role_grid_blocks = e->role_grid_blocks; c.role_dp_waves = gact::kRoleDp;
     c.ws_words_per_tile = (size_t)e->kp.ws_words;
     c.role_ws_words_per_block = gact::role_ws_words<gact::SplitLayoutLin<7, 13>>(1);
+    c.coop_ws_words_per_block = gact::coop_ws_words<gact::SplitLayoutLin<7, 13>>(1);
     return c;
 }
 
@@ -727,7 +731,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
     sl.routed_raw = 0;
     sl.overlapped = false;
     sl.lane = false;
-    sl.roles = false;
+    sl.roles = 0;
     // Is another slot of this engine still running?  Then this launch shares the machine (feeder threads, steps in
     // flight) and what counts is throughput: the wide layout -- faster per chain, slower per cell, made for a launch
     // that has the CUs to itself and lasts as long as its longest chain -- is not taken on its own account.
@@ -782,6 +786,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
             if constexpr (C == 20) {
                 switch (k) {
                 case M::RolesLin: if (two_sets) GACT_LAUNCH_MAIN((gact::extend_roles_kernel<RolesL, true>), brole); else GACT_LAUNCH_MAIN((gact::extend_roles_kernel<RolesL, false>), brole); break;
+                case M::CoopLin: if (two_sets) GACT_LAUNCH_MAIN((gact::extend_coop_kernel<RolesL, true>), b256); else GACT_LAUNCH_MAIN((gact::extend_coop_kernel<RolesL, false>), b256); break;
                 case M::SplitLin: if (two_sets) GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>), b256); else GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false>), b256); break;
                 case M::SplitLinTeam: GACT_LAUNCH_MAIN((extend_p16_kernel<gact::SplitLayoutLinTeam<7, 13>, false>), b256); break;
                 case M::WideLin: if (two_sets) GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayoutLin, false, true>), b256); else GACT_LAUNCH_MAIN((extend_p16_kernel<gact::WideLayoutLin, false>), b256); break;
@@ -884,7 +889,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
             q1.leave_longest = plan.leave_longest;
             if ((rc = launch_main(plan.main, true, plan.main_blocks, ln.stream, q1, ln.d_ws))) return rc;
             HIP_TRY(hipStreamWaitEvent(ln.stream, sl.aux_ev_b, 0));
-            if (first_pass) { sl.wide = false; sl.lin = true; sl.lane = plan.lane; sl.roles = plan.roles; }
+            if (first_pass) { sl.wide = false; sl.lin = true; sl.lane = plan.lane; sl.roles = plan.roles ? 1 : plan.coop ? 2 : 0; }
             sl.overlapped = true;
             return 0;
         }
@@ -894,7 +899,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         if (plan.seq == pol::Seq::SingleInt32) return 0;
         if (first_pass) HIP_TRY(hipEventRecord(sl.ev_mid, ln.stream));
         if ((rc = poison_lane(e, ln, 0x5bd1e995u))) return rc;      // the main launch reads nothing the seed launch stored
-        if (first_pass) { sl.wide = plan.wide; sl.lin = plan.lin; sl.aff = plan.aff; sl.roles = plan.roles; }
+        if (first_pass) { sl.wide = plan.wide; sl.lin = plan.lin; sl.aff = plan.aff; sl.roles = plan.roles ? 1 : plan.coop ? 2 : 0; }
         if (plan.seq == pol::Seq::CritLane) {
             // The critical lane beside a run's ONE split main launch (a run too small for overlapped seeding, e.g. the merged
             // forward-strand calls of eight feeder threads: 33 k chains on 24.6 k tile slots last as long as their longest
@@ -1136,6 +1141,7 @@ static bool derive_kernel_flags(gact_hip_engine *e)
     e->shared_hint = opt_env("no_shared_hint") == nullptr;
     e->overlap_seed = opt_env("no_overlap") == nullptr;
     e->roles = opt_env("roles") != nullptr && atoi(opt_env("roles")) != 0;
+    e->coop = opt_env("coop") != nullptr && atoi(opt_env("coop")) != 0;
     e->team_when_shared = opt_env("team_when_shared") != nullptr;
     e->static_prio = opt_env("static_prio") != nullptr;
     if (const char *v = opt_env("rank16")) e->rank16 = atoi(v);
@@ -2010,7 +2016,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
         st->merged_callers = e->slots[slot].merged_callers;
         st->overlapped_seeding = rec->overlapped ? 1 : 0;
         st->critical_lane = rec->lane ? 1 : 0;
-        st->role_waves = rec->roles ? 1 : 0;
+        st->role_waves = rec->roles;
         HIP_TRY(hipEventSynchronize(rec->ev_done));
         HIP_TRY(hipEventElapsedTime(&st->total_ms, rec->ev0, rec->ev1));
         st->main_ms = st->total_ms;
@@ -2040,7 +2046,7 @@ int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *st
     st->merged_callers = 1;
     st->overlapped_seeding = sl.overlapped ? 1 : 0;
     st->critical_lane = sl.lane ? 1 : 0;
-    st->role_waves = sl.roles ? 1 : 0;
+    st->role_waves = sl.roles;
     HIP_TRY(hipEventSynchronize(sl.ev1));
     HIP_TRY(hipEventElapsedTime(&st->total_ms, sl.ev0, sl.ev1));
     st->main_ms = st->total_ms;
@@ -2111,6 +2117,10 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates)
                                    e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
                 hipLaunchKernelGGL((gact::extend_p16_kernel<gact::SplitLayoutLin<7, 13>, false, true>), dim3(1), dim3(gact::kBlockThreads), 0, st,
                                    e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q2, sl.d_ws);
+                hipLaunchKernelGGL((gact::extend_coop_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(1), dim3(gact::kBlockThreads), 0, st,
+                                   e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
+                hipLaunchKernelGGL((gact::extend_coop_kernel<gact::SplitLayoutLin<7, 13>, true>), dim3(1), dim3(gact::kBlockThreads), 0, st,
+                                   e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q2, sl.d_ws);
                 if (e->role_grid_blocks > 0) {
                     hipLaunchKernelGGL((gact::extend_roles_kernel<gact::SplitLayoutLin<7, 13>, false>), dim3(1), dim3(gact::kRoleThreads), 0, st,
                                        e->kp, e->kc, d, d, d, 0, sl.overlaps.p, q, sl.d_ws);
@@ -2140,6 +2150,9 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
     } else if (n == "combine_window_us") {
         std::lock_guard<std::mutex> lk(e->cb.mu);
         e->cb.window_us = std::max(0, (int)value);
+    } else if (n == "coop") {
+        if (value != 0 && !(e->lin && e->split && e->C == 20)) return fail(GACT_HIP_EINVAL, "set_option: this engine has no split linear-gap launch");
+        e->coop = value != 0;
     } else if (n == "roles") {
         if (value != 0 && e->role_grid_blocks <= 0) return fail(GACT_HIP_EINVAL, "set_option: this engine was created without the role launch");
         e->roles = value != 0;
@@ -2170,6 +2183,7 @@ int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, 
         e.seed_grid_blocks = 2 * compute_units;
         e.role_grid_blocks = (e.lin && e.split && e.C == 20) ? compute_units : 0;
         if (flags & 4) e.roles = e.role_grid_blocks > 0;
+        if (flags & 8) e.coop = true;
         gact_policy::Inputs in;
         in.count = count; in.raw = (flags & 1) != 0; in.shared_machine = (flags & 2) != 0;
         t = gact_policy::describe(gact_policy::plan_pass(policy_caps(&e), in));
@@ -2294,6 +2308,13 @@ int gact_hip_debug_stamps(gact_hip_engine *e, unsigned long long *out8)
                           fc[1], (double)fc[0] / fc[1], (double)fc[2] / fc[1]);
     }
 #endif
+    {
+        unsigned long long cc[4], cz[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyFromSymbol(cc, HIP_SYMBOL(gact::g_coop_counts), sizeof cc));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_coop_counts), cz, sizeof cz));
+        if (cc[0]) printf("  cooperative walks: %llu batches, %.1f jobs and %.1f loop trips per batch, %.1f lanes walking per trip\n", cc[0],
+                          (double)cc[3] / cc[0], (double)cc[1] / cc[0], cc[1] ? (double)cc[2] / cc[1] : 0.0);
+    }
     unsigned long long wc[5], wz[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyFromSymbol(wc, HIP_SYMBOL(gact::g_walk_counts), sizeof wc));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(gact::g_walk_counts), wz, sizeof wz));

@@ -32,6 +32,8 @@ __device__ unsigned long long g_stamps2[8];
 __device__ unsigned long long g_timeline[4 * 4096];
 // shader clocks (s_memtime) each of those waves lived: with the 100 MHz stamps above, the clock the chip held
 __device__ unsigned long long g_wave_cycles[4096];
+// cooperative launch (gact_coop.hpp): walk batches, their loop trips, lane-trips (a trip with n walking lanes counts n), jobs walked
+__device__ unsigned long long g_coop_counts[4];
 #define GACT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
 #define GACT_ACC(slot, t0, t1) stamp_acc[slot] += (t1) - (t0)
 #else
@@ -641,7 +643,8 @@ __device__ __forceinline__ void cut_run(const uint32_t *seg_words, int bit0, int
 
 // COL::runs: the lane's slots as runs of consecutive DP columns -- first slot, slot count, and the column of the
 // run's first slot (which may be negative: pad columns left of the tile).
-template <int CT, int LANES, class COL>
+// WRITE_Q8 = false: the caller's walker cuts its bases out of the staged words (gact_coop.hpp) and keeps no query bytes
+template <int CT, int LANES, class COL, bool WRITE_Q8 = true>
 __device__ __forceinline__ void load_pair_packed(const SeqSetDev &rs, const SeqSetDev &qfwd, const SeqSetDev &qrc,
                                                  const PairTile &pt, int gl, uint8_t *ref8, int ref_bytes, int row0,
                                                  uint8_t *q8, int q_stride, uint32_t (&qb)[CT], uint32_t *stage, COL)
@@ -691,7 +694,7 @@ __device__ __forceinline__ void load_pair_packed(const SeqSetDev &rs, const SeqS
             for (int k = 0; k < N; k++) {
                 const int dq = c0 + k;
                 const bool real = (unsigned)dq < (unsigned)Q;
-                if (real) q8[h * q_stride + dq] = (uint8_t)(24u - qc[k] * 8u);
+                if (WRITE_Q8 && real) q8[h * q_stride + dq] = (uint8_t)(24u - qc[k] * 8u);
                 const uint32_t keep = h ? 0xff00ffffu : 0xffffff00u;
                 const uint32_t mine = (h ? qb[S0 + k] : kPermZero * 0x01010101u);       // tile A initialises the selector
                 qb[S0 + k] = real ? (mine & keep) | ((qc[k] + 4u * h) << (16 * h)) : mine;

@@ -29,7 +29,7 @@ struct Caps {                    // fixed at gact_hip_create
     int C = 20;
     bool p16 = false, seed16 = false, lin = false, aff = false, aff_seed = true, split = false, tagged = false;
     bool mismatch_below_extend = false;
-    bool roles = false, overlap_seed = true, crit_lane = true, crit_lane_always = false, lane_small = false, team_when_shared = false;
+    bool roles = false, coop = false, overlap_seed = true, crit_lane = true, crit_lane_always = false, lane_small = false, team_when_shared = false;
     int lane_small_factor = 3, lane_blocks = 0;
     int wide = 0;                // 0 auto, 1 always, -1 never
     int wide_blocks_per_cu = 0;
@@ -37,7 +37,7 @@ struct Caps {                    // fixed at gact_hip_create
     int grid_blocks = 0, seed_grid_blocks = 0, seed_lin_grid_blocks = 0, lin_grid_blocks = 0, aff_grid_blocks = 0,
         wide_lin_grid_blocks = 0, role_grid_blocks = 0;
     int role_dp_waves = 10;      // DP waves of a role block (gact_roles.hpp kRoleDp)
-    size_t ws_words_per_tile = 0, role_ws_words_per_block = 0;
+    size_t ws_words_per_tile = 0, role_ws_words_per_block = 0, coop_ws_words_per_block = 0;
 };
 
 struct Inputs {                  // of one pass
@@ -50,14 +50,14 @@ struct Inputs {                  // of one pass
 
 enum class Seq { SingleInt32, Plain, Overlapped, CritLane };
 enum class SeedK { Int32, P16Raw, P16, P16Lin, P16Aff, P16AffNeg };
-enum class MainK { None, RolesLin, SplitLin, SplitLinTeam, WideLin, SplitAffNeg, SplitAff, WideTaggedRaw, WideTagged, WideRaw, Wide,
+enum class MainK { None, RolesLin, CoopLin, SplitLin, SplitLinTeam, WideLin, SplitAffNeg, SplitAff, WideTaggedRaw, WideTagged, WideRaw, Wide,
                    SplitTaggedRaw, SplitTagged, SplitRaw, Split, UniformTaggedRaw, UniformTagged, UniformRaw, Uniform };
 
 struct Plan {
     Seq seq = Seq::Plain;
     SeedK seed = SeedK::Int32;
     MainK main = MainK::None;
-    bool wide = false, lin = false, aff = false, roles = false;
+    bool wide = false, lin = false, aff = false, roles = false, coop = false;
     int seed_blocks = 0, main_blocks = 0;
     // Overlapped: seed A takes the longest nA of the ordered list; main 1 / seed B + main 2 side by side
     int nA = 0, seedB_blocks = 0, main2_blocks = 0;
@@ -91,10 +91,11 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
         p.roles = c.roles && c.role_grid_blocks > 0;
         const int main1 = c.lin_grid_blocks * 2 / 3, main2 = c.lin_grid_blocks - main1;
         const int role1 = c.role_grid_blocks * 2 / 3, role2 = c.role_grid_blocks - role1;
-        p.main = p.roles ? MainK::RolesLin : MainK::SplitLin;
+        p.coop = !p.roles && c.coop;
+        p.main = p.roles ? MainK::RolesLin : p.coop ? MainK::CoopLin : MainK::SplitLin;
         p.main_blocks = p.roles ? role1 : main1;
         p.main2_blocks = p.roles ? role2 : main2;
-        p.ws_split = p.roles ? (size_t)role1 * c.role_ws_words_per_block : ws_words_for(c, main1);
+        p.ws_split = p.roles ? (size_t)role1 * c.role_ws_words_per_block : p.coop ? (size_t)main1 * c.coop_ws_words_per_block : ws_words_for(c, main1);
         // seed launch B runs on a third of the machine, and until it has ended main launch 1 gets no new chains: it is given
         // what it can seed in a few milliseconds, two candidates per resident tile slot; a larger run seeds the rest in A
         p.nA = std::max(std::min(count, main1 * kNarrowTilesPerBlock), count - 2 * narrow_slots0);
@@ -134,9 +135,11 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     p.lin = c.lin && !in.raw && (p.wide || c.split);
     p.aff = c.aff && !in.raw && !p.wide && c20;
     p.roles = c20 && c.roles && c.role_grid_blocks > 0 && p.lin && !p.wide && !(in.shared_machine && in.own_lane && c.team_when_shared);
+    p.coop = c20 && c.coop && p.lin && !p.wide && !p.roles && !(in.shared_machine && in.own_lane && c.team_when_shared);
     const bool tg = c.tagged, raw = in.raw;
     p.main = p.lin ? (p.wide ? MainK::WideLin
                              : p.roles ? MainK::RolesLin
+                             : p.coop ? MainK::CoopLin
                                        : (in.shared_machine && in.own_lane && c.team_when_shared) ? MainK::SplitLinTeam : MainK::SplitLin)
            : p.aff ? (c.mismatch_below_extend ? MainK::SplitAffNeg : MainK::SplitAff)
            : p.wide ? (tg ? (raw ? MainK::WideTaggedRaw : MainK::WideTagged) : (raw ? MainK::WideRaw : MainK::Wide))
@@ -164,7 +167,7 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
             p.lane = true;
             p.main2_blocks = lane_blocks;
             p.main_blocks = grid(ceil_div(groups_needed, 4), c.lin_grid_blocks - lane_blocks);
-            p.ws_split = ws_words_for(c, c.lin_grid_blocks - lane_blocks);
+            p.ws_split = p.coop ? (size_t)(c.lin_grid_blocks - lane_blocks) * c.coop_ws_words_per_block : ws_words_for(c, c.lin_grid_blocks - lane_blocks);
             p.leave_longest = lane_blocks * kWideTilesPerBlock;
             return p;
         }
@@ -196,7 +199,8 @@ inline const char *name(SeedK k)
 inline const char *name(MainK k)
 {
     switch (k) {
-    case MainK::None: return "-"; case MainK::RolesLin: return "roles<SplitLayoutLin>"; case MainK::SplitLin: return "SplitLayoutLin";
+    case MainK::None: return "-"; case MainK::RolesLin: return "roles<SplitLayoutLin>"; case MainK::CoopLin: return "coop<SplitLayoutLin>";
+    case MainK::SplitLin: return "SplitLayoutLin";
     case MainK::SplitLinTeam: return "SplitLayoutLinTeam"; case MainK::WideLin: return "WideLayoutLin"; case MainK::SplitAffNeg: return "SplitLayoutAff<cbneg>";
     case MainK::SplitAff: return "SplitLayoutAff"; case MainK::WideTaggedRaw: return "WideLayoutTagged<raw>"; case MainK::WideTagged: return "WideLayoutTagged";
     case MainK::WideRaw: return "WideLayout<raw>"; case MainK::Wide: return "WideLayout"; case MainK::SplitTaggedRaw: return "SplitLayout<tag,raw>";
@@ -211,9 +215,10 @@ inline std::string describe(const Plan &p)
     char b[512];
     snprintf(b, sizeof b, "{\"sequence\": \"%s\", \"seed_kernel\": \"%s\", \"seed_blocks\": %d, \"main_kernel\": \"%s\", \"main_blocks\": %d, "
                           "\"second_main_blocks\": %d, \"seed_b_blocks\": %d, \"n_a\": %d, \"critical_lane\": %s, \"leave_longest\": %d, "
-                          "\"ws_split_words\": %zu, \"wide\": %s, \"linear\": %s, \"affine_drift\": %s, \"roles\": %s}",
+                          "\"ws_split_words\": %zu, \"wide\": %s, \"linear\": %s, \"affine_drift\": %s, \"roles\": %s, \"coop\": %s}",
              name(p.seq), name(p.seed), p.seed_blocks, name(p.main), p.main_blocks, p.main2_blocks, p.seedB_blocks, p.nA, p.lane ? "true" : "false",
-             p.leave_longest, p.ws_split, p.wide ? "true" : "false", p.lin ? "true" : "false", p.aff ? "true" : "false", p.roles ? "true" : "false");
+             p.leave_longest, p.ws_split, p.wide ? "true" : "false", p.lin ? "true" : "false", p.aff ? "true" : "false", p.roles ? "true" : "false",
+             p.coop ? "true" : "false");
     return b;
 }
 

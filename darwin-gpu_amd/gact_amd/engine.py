@@ -14,7 +14,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libgact_hip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
            ("gact_engine.hip", "gact_kernels.hpp", "gact_device.hpp", "gact_chain.hpp", "gact_p16.hpp", "gact_p16s.hpp", "gact_lin.hpp",
-            "gact_aff.hpp", "gact_roles.hpp", "gact_policy.hpp", "gact_big.hpp", "gact_gather.hpp", "dsoft_device.hpp", "dsoft_engine.hpp")] + \
+            "gact_aff.hpp", "gact_roles.hpp", "gact_coop.hpp", "gact_policy.hpp", "gact_big.hpp", "gact_gather.hpp", "dsoft_device.hpp", "dsoft_engine.hpp")] + \
           [os.path.join(_ROOT, "include", "gact_hip.h")]
 
 SET_REF, SET_QUERY, SET_QUERY_RC = 0, 1, 2
@@ -423,7 +423,7 @@ class Engine:
                 "tagged_pointers": bool(st.tagged_pointers), "linear_gap": st.linear_gap == 1, "affine_drift": st.linear_gap == 2,
                 "handed_off": st.handed_off, "seed_cells": st.seed_cells, "raw_candidates": st.raw_candidates,
                 "band_redos": st.band_redos, "merged_callers": st.merged_callers, "overlapped_seeding": bool(st.overlapped_seeding),
-                "critical_lane": bool(st.critical_lane), "role_waves": bool(st.role_waves)}
+                "critical_lane": bool(st.critical_lane), "role_waves": st.role_waves == 1, "coop_walks": st.role_waves == 2}
 
     def measure_valu_rate(self):
         v = C.c_double()

@@ -115,10 +115,10 @@ def record_crcs(rec):
 CONFIG4_BLOCKS = 8        # BASELINE config 4 in the form one node runs it: eight pacbio50mb genome blocks, 40,000 reads, 418 Mb
 
 
-def config4_blocks(mine, candidates="dsoft"):
+def config4_blocks(mine, candidates="dsoft", name="pacbio50mb"):
     """the genome blocks `mine` (indices) of the config-4 job: [(index, (reads, cands_fwd, cands_rc))]"""
     out = []
     for b in mine:
-        blk = make_block("pacbio50mb", block=b, candidates=candidates)
+        blk = make_block(name, block=b, candidates=candidates)
         out.append((b, (blk.rs.reads, blk.cf, blk.cr)))
     return out

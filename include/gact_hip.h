@@ -286,8 +286,9 @@ typedef struct {
                                            alone and main_ms holds the rest */
     int32_t critical_lane;              /* 1: beside the split main launch a wide one ran on a third of the blocks and took the
                                            longest chains (runs of 1-4 chains per tile slot on an otherwise idle engine) */
-    int32_t role_waves;                 /* 1: the split linear-gap main launch ran as DP waves + walker waves (the traceback walk of a
-                                           tile on another wave while its DP wave runs the pass of a second bank of tiles) */
+    int32_t role_waves;                 /* how the split linear-gap main launch walked its tracebacks: 0 every wave its own eight tiles
+                                           behind their pass; 1 DP waves + walker waves (gact_roles.hpp); 2 two banks of tiles per wave,
+                                           walks of the whole block batched on whichever wave needs a result first (gact_coop.hpp) */
 } gact_hip_run_stats;
 int gact_hip_last_run_stats(gact_hip_engine *e, int slot, gact_hip_run_stats *stats);
 
@@ -307,6 +308,8 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *   "runs_in_flight"     1: the caller keeps several runs in flight on this engine (a pipeline of steps, one slot each): every
  *                        launch takes the layout with the better throughput.  0 (default): the engine looks at the other slots'
  *                        events when a run is launched, which the first launches of a pipeline answer differently from run to run
+ *   "coop"               1: the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback
+ *                        walks (gact_hip_run_stats.role_waves == 2); 0 (default)
  *   "roles"              1: the split linear-gap main launch runs as DP waves + walker waves (gact_hip_run_stats.role_waves);
  *                        0 (default): one wave does everything for its tiles.  Same records; measured no faster
  * Every other switch of the library is read once, in gact_hip_create, from an environment variable; set_option names the

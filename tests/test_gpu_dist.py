@@ -45,6 +45,43 @@ def test_bench_force_dist_as_a_child_process(slots, steps):
     assert cg["records_per_rank"] == [res["config"]["candidates"]]
 
 
+def _two_ranks_on_one_device(extra, timeout=900):
+    """bench.py as two processes (world 2) on the one GPU of a test box: gloo on host tensors stands in for RCCL, which
+    refuses two ranks on one device; everything else -- block building per rank, exchange, deal, engine per rank, steps in
+    flight, the gather in launch order, the checksums -- is the code the driver's 8-GPU run executes"""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   LOCAL_WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-device"] + extra,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-1500:] + se[-3000:]
+    return json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+
+
+def test_two_ranks_on_one_device_weak_scaling_path():
+    res = _two_ranks_on_one_device(["--workload", "ecoli10x_small", "--steps", "5", "--warmup", "1", "--cpu-seconds", "2", "--slots", "4"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["slots_in_flight"] == 4
+    assert "rehearsal" in res["config"]
+    g = res["config"]["gather"]
+    assert g["ranks"] == 2 and len(g["records_per_rank"]) == 2 and min(g["records_per_rank"]) > 1000
+    assert res["config"]["gathered_records"] == res["config"]["candidates"] == sum(g["records_per_rank"])
+    assert len(g["crc32_per_rank"]) == 2 and res["parity"]["bit_exact"] is True
+
+
+def test_two_ranks_on_one_device_strong_scaling_path():
+    """--scaling strong: a FIXED job of eight blocks (small ones here), rank r builds blocks r, r + 2, ..., four exchange rounds,
+    the merged list dealt over the two ranks"""
+    res = _two_ranks_on_one_device(["--scaling", "strong", "--strong-blocks-of", "ecoli10x_small", "--steps", "3", "--warmup", "1", "--slots", "2"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong"
+    c4 = res["config4_strong"]
+    assert c4["n_gpus"] == 2 and len(c4["per_rank_ms_per_step"]["all"]) == 2 and c4["gather_ms_per_step_rank0"] is not None
+    assert c4["candidates"] > 8 * 2000 and c4["cells_per_step"] > 0 and len(c4["build_seconds_per_rank"]) == 2
+
+
 SCRIPT = r"""
 import sys
 sys.path[:0] = [%r, %r]

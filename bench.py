@@ -146,6 +146,8 @@ def main_kernel_name(st):
                 "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutLin>"}[name]
         if st.get("role_waves"):        # DP waves + walker waves (gact_roles.hpp)
             name = name.replace("extend_p16_kernel", "extend_roles_kernel")
+        elif st.get("coop_walks"):      # two banks per wave, cooperative batched walks (gact_coop.hpp)
+            name = name.replace("extend_p16_kernel", "extend_coop_kernel")
     elif st.get("affine_drift"):        # the drifted affine pass (gact_aff.hpp), split layout
         name = "extend_p16_kernel<SplitLayoutAff<7,13>>"
     elif st["tagged_pointers"]:         # pointer phase on tagged scores: the layouts' TAG variants
@@ -777,7 +779,7 @@ def config4_strong(args, dist, torch, rank, world, local_rank, use_dist, steps, 
         "per_rank_ms_per_step": {"min": round(min(per_rank_ms), 3), "max": round(max(per_rank_ms), 3), "all": [round(x, 3) for x in per_rank_ms]},
         "gather_ms_per_step_rank0": gather_ms,
         "single_run_ms_per_rank": {"min": round(min(per_rank_single), 2), "max": round(max(per_rank_single), 2)},
-        "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else "") + ("-roles" if st.get("role_waves") else ""),
+        "kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else "") + ("-roles" if st.get("role_waves") else "-coop" if st.get("coop_walks") else ""),
         "kernel_ms": round(st["main_ms"], 3), "seed_kernel_ms": round(st["seed_ms"], 3),
         "parity": dict(all_checked, bit_exact=True, golden="tests/golden/config_config4_rank{0,5}.npz (every record of two ranks of eight, from the oracle)"),
         "build_seconds_per_rank": builds,
@@ -1125,8 +1127,8 @@ def timed_config(head, cat, offs, rcat, roffs, cf, cr, scoring=(1, -1, -1, -1)):
                 "raw_byte_candidates": int(st["raw_candidates"]),
                 "tiles": int(rec["n_tiles"].sum()), "cells_per_step": cells,
                 # (a launch made while another slot is running takes the layout with the better throughput)
-                "kernel_layout": flight["layout"] + ("-lin" if flight["linear_gap"] else "-aff" if flight.get("affine_drift") else ""),
-                "single_slot_kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else "-aff" if st.get("affine_drift") else ""),
+                "kernel_layout": flight["layout"] + ("-lin" if flight["linear_gap"] else "-aff" if flight.get("affine_drift") else "") + ("-coop" if flight.get("coop_walks") else ""),
+                "single_slot_kernel_layout": st["layout"] + ("-lin" if st["linear_gap"] else "-aff" if st.get("affine_drift") else "") + ("-coop" if st.get("coop_walks") else ""),
                 "kernel_ms": round(float(np.mean([x["main_ms"] for x in stats])), 3),
                 "seed_kernel_ms": round(float(np.mean([x["seed_ms"] for x in stats])), 3),
                 "parity": {"checked_candidates": int(checked), "bit_exact": True}})

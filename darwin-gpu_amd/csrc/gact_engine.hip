@@ -178,6 +178,9 @@ struct Slot {
     int stream_index = -1;              // of `stream` in the process's pool (StreamPool)
     int64_t routed_key[4] = {-1, -1, -1, -1};   // (first, n, rc_from, sets_epoch) routed_host was counted for
     int routed_host[2] = {0, 0};        // candidates of that range whose reads are plain A/C/G/T / the rest (launch_extend)
+    int64_t est_key[4] = {-1, -1, -1, -1};      // (first, n, rc_from, sets_epoch) the chain-length estimates below were made for
+    int est_tiles_max = 0;              // tiles the longest chain of that range can have, and of all its chains together
+    long long est_tiles_sum = 0;
     gact_candidate *h_stage = nullptr;  // pinned staging for candidates_upload: hipMemcpyAsync from the caller's pageable array
     size_t h_stage_cap = 0;             // has the runtime pin those pages first, and with eight feeder threads at it at once
                                         // that call took 8 ms for some of them (profiles/r04/upload_trace_*.txt)
@@ -248,7 +251,7 @@ static const OptionDef kOptions[] = {
     {"no_tagged", "GACT_HIP_NO_TAGGED", 'c', 'k', "explicit pointer comparisons instead of tagged scores"},
     {"no_lin", "GACT_HIP_NO_LIN", 'c', 'k', "the affine passes also for linear scorings (gact_lin.hpp off)"},
     {"no_aff", "GACT_HIP_NO_AFF", 'c', 'k', "round 1's tagged affine pass instead of the drifted one (gact_aff.hpp off)"},
-    {"coop", "GACT_HIP_COOP", 'l', 'k', "1: the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback walks (gact_coop.hpp)"},
+    {"coop", "GACT_HIP_COOP", 'l', 'k', "the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback walks (gact_coop.hpp): 1 always, 0 never, 2 / unset where throughput bounds the launch"},
     {"roles", "GACT_HIP_ROLES", 'l', 'k', "1: the split linear-gap main launch as DP waves + walker waves (gact_roles.hpp; default 0: measured no faster, DESIGN 3.13)"},
     {"no_routing", "GACT_HIP_NO_ROUTING", 'c', 'k', "a set with a non-ACGT byte moves the whole launch onto the raw-byte kernels"},
     {"no_side_lane", "GACT_HIP_NO_SIDE_LANE", 'c', 's', "routed raw-byte launches after the 2-bit ones instead of beside them"},
@@ -360,7 +363,8 @@ struct gact_hip_engine {
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
     bool roles = false;         // GACT_HIP_ROLES=1 / set_option "roles": the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
     int role_grid_blocks = 0;   // ... and its persistent grid (blocks of kRoleThreads)
-    bool coop = false;          // GACT_HIP_COOP=1 / set_option "coop": ... with two banks of tiles per wave and cooperative, batched walks (gact_coop.hpp)
+    int coop = 0;               // GACT_HIP_COOP / set_option "coop": two banks of tiles per wave and cooperative, batched walks (gact_coop.hpp):
+                                // 0 where throughput bounds the launch (gact_policy.hpp), 1 always, -1 never
     int aff_grid_blocks = 0;    // ... of the drifted affine split launch (two blocks per CU)
     int wide_lin_grid_blocks = 0;       // ... of the linear-gap wide launch
     gact::P16Consts kc;
@@ -694,7 +698,7 @@ gact_policy::Caps policy_caps(const gact_hip_engine *e)
     gact_policy::Caps c;
     c.C = e->C; c.p16 = e->p16; c.seed16 = e->seed16; c.lin = e->lin; c.aff = e->aff; c.aff_seed = e->aff_seed; c.split = e->split; c.tagged = e->tagged;
     c.mismatch_below_extend = e->params.mismatch < e->params.gap_extend;
-    c.roles = e->roles; c.coop = e->coop && e->lin && e->split && e->C == 20; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
+    c.roles = e->roles; c.coop = (e->lin && e->split && e->C == 20) ? e->coop : -1; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
     c.lane_small = e->lane_small; c.lane_small_factor = e->lane_small_factor; c.lane_blocks = e->lane_blocks; c.team_when_shared = e->team_when_shared;
     c.wide = e->wide; c.wide_blocks_per_cu = e->wide_blocks_per_cu; c.cus = e->prop.multiProcessorCount;
     c.grid_blocks = e->grid_blocks; c.seed_grid_blocks = e->seed_grid_blocks; c.seed_lin_grid_blocks = e->seed_lin_grid_blocks;
@@ -754,6 +758,30 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         fprintf(stderr, "done (popped %d)\n", dbg[0]);
         return 0;
     };
+    // What the chains of this range can be at most, where the host holds the list and the run is small enough for the choice of
+    // layout to hang on it (gact_policy.hpp layout_times): bases left and right of every seed hit, in tiles (gact.cpp:82-195: a
+    // tile advances a chain by at most `early` bases)
+    int est_tiles_max = 0;
+    long long est_tiles_sum = 0;
+    if (strands < 0 && !sl.h_cands.empty() && (size_t)first + (size_t)n <= sl.h_cands.size() && n <= e->grid_blocks * 32 && e->lin && e->split) {
+        const int64_t key[4] = {first, n, rc_from, e->sets_epoch};
+        if (memcmp(key, sl.est_key, sizeof key)) {
+            const int early = std::max(1, e->kp.early);
+            int mx = 0; long long sum = 0;
+            for (int k = first; k < first + n; k++) {
+                const gact_candidate &c = sl.h_cands[(size_t)k];
+                const SeqSet &qs = k >= rc_from ? qr : qf;
+                const int64_t rl = rs.h_offsets[(size_t)c.ref_id + 1] - rs.h_offsets[(size_t)c.ref_id];
+                const int64_t ql = qs.h_offsets[(size_t)c.query_id + 1] - qs.h_offsets[(size_t)c.query_id];
+                const int64_t left = std::min<int64_t>(c.ref_pos, c.query_pos), right = std::min<int64_t>(rl - c.ref_pos, ql - c.query_pos);
+                const int tiles = (int)((std::max<int64_t>(left, 0) + std::max<int64_t>(right, 0)) / early) + 2;
+                mx = std::max(mx, tiles); sum += tiles;
+            }
+            memcpy(sl.est_key, key, sizeof key);
+            sl.est_tiles_max = mx; sl.est_tiles_sum = sum;
+        }
+        est_tiles_max = sl.est_tiles_max; est_tiles_sum = sl.est_tiles_sum;
+    }
     // second_set: the pass files and pops its chains in the lane's second set of queues (the raw-byte pass behind the 2-bit
     // one on the same lane: the first set keeps its counts for the statistics, nothing is cleared between the passes).
     // WHAT the pass runs as -- kernels, grids, sequence -- is gact_policy::plan_pass's answer (gact_policy.hpp: a pure function
@@ -763,6 +791,7 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         pol::Inputs in;
         in.count = count; in.raw = raw; in.listed = list != nullptr; in.second_set = second_set; in.shared_machine = shared_machine;
         in.own_lane = ln.stream == sl.stream; in.trace = trace; in.poison = e->poison != 0; in.lane_max_blocks = ln.max_blocks;
+        if (!list && !second_set) { in.est_tiles_max = est_tiles_max; in.est_tiles_sum = est_tiles_sum; }
         const pol::Plan plan = pol::plan_pass(policy_caps(e), in);
         const gact::SeqSetDev d_rs = rs.dev(raw), d_qf = qf.dev_or(raw, rs), d_qr = qr.dev_or(raw, rs);
         gact::ChainQueues cq = second_set ? second_queues(ln, sl) : queues(ln, sl);
@@ -1141,7 +1170,7 @@ static bool derive_kernel_flags(gact_hip_engine *e)
     e->shared_hint = opt_env("no_shared_hint") == nullptr;
     e->overlap_seed = opt_env("no_overlap") == nullptr;
     e->roles = opt_env("roles") != nullptr && atoi(opt_env("roles")) != 0;
-    e->coop = opt_env("coop") != nullptr && atoi(opt_env("coop")) != 0;
+    if (const char *v = opt_env("coop")) e->coop = atoi(v) == 1 ? 1 : atoi(v) == 0 ? -1 : 0;
     e->team_when_shared = opt_env("team_when_shared") != nullptr;
     e->static_prio = opt_env("static_prio") != nullptr;
     if (const char *v = opt_env("rank16")) e->rank16 = atoi(v);
@@ -2152,7 +2181,7 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
         e->cb.window_us = std::max(0, (int)value);
     } else if (n == "coop") {
         if (value != 0 && !(e->lin && e->split && e->C == 20)) return fail(GACT_HIP_EINVAL, "set_option: this engine has no split linear-gap launch");
-        e->coop = value != 0;
+        e->coop = value == 1 ? 1 : value == 0 ? -1 : 0;
     } else if (n == "roles") {
         if (value != 0 && e->role_grid_blocks <= 0) return fail(GACT_HIP_EINVAL, "set_option: this engine was created without the role launch");
         e->roles = value != 0;
@@ -2183,9 +2212,13 @@ int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, 
         e.seed_grid_blocks = 2 * compute_units;
         e.role_grid_blocks = (e.lin && e.split && e.C == 20) ? compute_units : 0;
         if (flags & 4) e.roles = e.role_grid_blocks > 0;
-        if (flags & 8) e.coop = true;
+        e.coop = (flags & 8) ? 1 : (flags & 16) ? -1 : 0;
         gact_policy::Inputs in;
         in.count = count; in.raw = (flags & 1) != 0; in.shared_machine = (flags & 2) != 0;
+        // (bits 8-19: tiles of the longest chain the list can make, bits 20-31: mean tiles per chain -- what the host works out
+        //  of a list it holds; 0: unknown)
+        in.est_tiles_max = (flags >> 8) & 0xfff;
+        in.est_tiles_sum = (long long)((flags >> 20) & 0xfff) * count;
         t = gact_policy::describe(gact_policy::plan_pass(policy_caps(&e), in));
     }
     if (buf && cap > 0) {

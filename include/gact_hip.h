@@ -308,8 +308,9 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *   "runs_in_flight"     1: the caller keeps several runs in flight on this engine (a pipeline of steps, one slot each): every
  *                        launch takes the layout with the better throughput.  0 (default): the engine looks at the other slots'
  *                        events when a run is launched, which the first launches of a pipeline answer differently from run to run
- *   "coop"               1: the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback
- *                        walks (gact_hip_run_stats.role_waves == 2); 0 (default)
+ *   "coop"               the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback
+ *                        walks (gact_hip_run_stats.role_waves == 2): 1 always, 0 never, 2 (default) where throughput bounds the
+ *                        launch -- it shares the machine, or has six chains and more per resident tile slot
  *   "roles"              1: the split linear-gap main launch runs as DP waves + walker waves (gact_hip_run_stats.role_waves);
  *                        0 (default): one wave does everything for its tiles.  Same records; measured no faster
  * Every other switch of the library is read once, in gact_hip_create, from an environment variable; set_option names the
@@ -321,7 +322,9 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value);
 int64_t gact_hip_options_describe(char *buf, int64_t cap);
 /* The launch plan -- sequence, kernels, grids -- that an engine of parameters p makes for one pass over `count` candidates on a
  * device of compute_units CUs (kernels at their nominal occupancy), as one JSON object.  flags: bit 0 = the read sets hold
- * bytes other than A/C/G/T, bit 1 = the launch shares the machine (other runs in flight), bit 2 = role launch on.
+ * bytes other than A/C/G/T, bit 1 = the launch shares the machine (other runs in flight), bit 2 = role launch on, bit 3 =
+ * cooperative launch always, bit 4 = never (neither: where the policy takes it); bits 8-19 = tiles of the longest chain the list can make, bits 20-31 = mean tiles per chain (what the
+ * engine works out of a list the host holds; 0: unknown -- the layout of a small run is then chosen by the count alone).
  * The policy is a pure function (csrc/gact_policy.hpp); this entry exists so that it can be swept and tested without a
  * device.  Same buffer convention as gact_hip_options_describe. */
 int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, int32_t count, int32_t flags, char *buf, int64_t cap);

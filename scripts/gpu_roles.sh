@@ -8,7 +8,7 @@ if [ -n "${TESTS-tests/test_gpu_chain.py tests/test_gpu_golden.py tests/test_gpu
 fi
 if [ -f $R/build/libgact_hip_stamps.so ] && [ -z "$NO_STAMPS" ]; then
   for w in ${STAMP_WORKLOADS:-ecoli10x}; do
-    GACT_HIP_${MODE_ENV:-ROLES}=1 GACT_STAMPS_LIB=$R/build/libgact_hip_stamps.so timeout -k 10 200 python $R/tools/stamps.py $w > $OUT/stamps_${w}_roles.txt 2>&1; echo "== stamps $w roles"; cat $OUT/stamps_${w}_roles.txt | tail -22
+    env GACT_HIP_${MODE_ENV:-ROLES}=1 GACT_STAMPS_LIB=$R/build/libgact_hip_stamps.so timeout -k 10 200 python $R/tools/stamps.py $w > $OUT/stamps_${w}_roles.txt 2>&1; echo "== stamps $w roles"; cat $OUT/stamps_${w}_roles.txt | tail -22
     GACT_HIP_ROLES=0 GACT_STAMPS_LIB=$R/build/libgact_hip_stamps.so timeout -k 10 200 python $R/tools/stamps.py $w > $OUT/stamps_${w}_old.txt 2>&1; echo "== stamps $w old"; cat $OUT/stamps_${w}_old.txt | tail -22
   done
 fi

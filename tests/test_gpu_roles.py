@@ -73,6 +73,7 @@ def test_role_launch_equals_the_oracle_and_the_old_launch(monkeypatch, reads_and
         _same(got, want, "%s launch, run %d" % (mode, rep))
     eng.close()
     monkeypatch.delenv({"roles": "GACT_HIP_ROLES", "coop": "GACT_HIP_COOP"}[mode])
+    monkeypatch.setenv("GACT_HIP_COOP", "0")
     eng = engine.Engine()
     _load(eng, rs)
     eng.candidates_upload(cands)

@@ -64,14 +64,18 @@ def test_launch_policy_operating_points():
     for n, seq, main in ((1, "seed+main", "WideLayoutLin"), (S, "seed+main", "WideLayoutLin"),
                          (S + 1, "seed+main+critical-lane", "SplitLayoutLin"), (S + S // 2 - 1, "seed+main+critical-lane", "SplitLayoutLin"),
                          (S + S // 2, "overlapped-seeding", "SplitLayoutLin"), (4 * S, "overlapped-seeding", "SplitLayoutLin"),
-                         (4 * S + 1, "seed+main", "SplitLayoutLin"), (3_000_000, "seed+main", "SplitLayoutLin")):
+                         (4 * S + 1, "seed+main", "SplitLayoutLin"), (6 * S - 1, "seed+main", "SplitLayoutLin"),
+                         (6 * S, "seed+main", "coop<SplitLayoutLin>"), (3_000_000, "seed+main", "coop<SplitLayoutLin>")):
         p = _plan(n)
         assert (p["sequence"], p["main_kernel"]) == (seq, main), (n, p)
         assert p["seed_kernel"] == "seed_p16<lin>" and p["linear"] and not p["roles"]
-    # a launch that shares the machine: the throughput layout on two thirds of the blocks, no second stream, whatever the count
+    # a launch that shares the machine: the throughput layout -- two banks per wave, cooperative walks -- on two thirds of the
+    # blocks, no second stream, whatever the count; "coop" 0 keeps the one-wave-does-all launch
     for n in (100, S, 2 * S, 10 * S):
         p = _plan(n, flags=2)
-        assert p["sequence"] == "seed+main" and p["main_kernel"] == "SplitLayoutLin" and p["main_blocks"] <= 512, (n, p)
+        assert p["sequence"] == "seed+main" and p["main_kernel"] == "coop<SplitLayoutLin>" and p["main_blocks"] <= 512, (n, p)
+        assert _plan(n, flags=2 | 16)["main_kernel"] == "SplitLayoutLin"
+    assert _plan(2 * S, flags=8)["main_kernel"] == "coop<SplitLayoutLin>" and _plan(2 * S, flags=8)["sequence"] == "overlapped-seeding"
     # the role launch: one block of twelve waves per CU, in the same sequences
     p = _plan(2 * S, flags=4)
     assert p["main_kernel"] == "roles<SplitLayoutLin>" and p["main_blocks"] + p["second_main_blocks"] == 256 and p["roles"]
@@ -99,7 +103,7 @@ def test_launch_policy_is_sane_over_a_sweep_of_counts():
         for flags in (0, 2, 4):
             p = _plan(n, flags=flags)
             assert 1 <= p["seed_blocks"] <= 3 * cus and 1 <= p["main_blocks"] <= 3 * cus and p["second_main_blocks"] <= cus
-            per_block = 16 if p["wide"] else 160 if p["roles"] else 32
+            per_block = 16 if p["wide"] else 160 if p["roles"] else 64 if p["coop"] else 32
             slots = (p["main_blocks"] + (p["second_main_blocks"] if not p["critical_lane"] else 0)) * per_block
             if p["critical_lane"]:
                 slots += p["second_main_blocks"] * 16

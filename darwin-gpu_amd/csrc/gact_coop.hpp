@@ -316,6 +316,24 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_coop_kernel(
             if (w.gl == 0) bank_lds[group_in_block][bank][4] = 0;
             wave_sync();
         }
+        // ---- the queues are empty: chains move out of bank 1 into free slots of bank 0, so that what is left of the launch runs
+        //      one bank per wave -- a chain then advances once per pass + walk, not once per two passes (with both banks
+        //      in use to the end the launch of ecoli10x ran 37 ms where its queues were empty after 25).  Bank 1's chains are at
+        //      rest here (their results have just been consumed); a free slot of bank 0 has no job in flight even while bank 0
+        //      has, and its next pick finds the chain.
+        if (bank == 1 && exhausted) {
+            ChainState *st0 = chain_lds[group_in_block][0];
+#pragma unroll
+            for (int h = 0; h < kSlots; h++) {
+                const int ph1 = st[h].phase, f0 = st0[0].phase == 2 ? 0 : st0[1].phase == 2 ? 1 : -1;
+                wave_sync();
+                if (ph1 != 2 && f0 >= 0 && w.gl == 0) {
+                    st0[f0] = st[h];
+                    st[h].phase = 2; st[h].cand = -1;
+                }
+                wave_sync();
+            }
+        }
         GACT_STAMP(t_a);
         // ---- control phase: both slots of the bank pick their next tile
         PairTile pt;

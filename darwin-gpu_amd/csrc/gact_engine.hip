@@ -178,9 +178,6 @@ struct Slot {
     int stream_index = -1;              // of `stream` in the process's pool (StreamPool)
     int64_t routed_key[4] = {-1, -1, -1, -1};   // (first, n, rc_from, sets_epoch) routed_host was counted for
     int routed_host[2] = {0, 0};        // candidates of that range whose reads are plain A/C/G/T / the rest (launch_extend)
-    int64_t est_key[4] = {-1, -1, -1, -1};      // (first, n, rc_from, sets_epoch) the chain-length estimates below were made for
-    int est_tiles_max = 0;              // tiles the longest chain of that range can have, and of all its chains together
-    long long est_tiles_sum = 0;
     gact_candidate *h_stage = nullptr;  // pinned staging for candidates_upload: hipMemcpyAsync from the caller's pageable array
     size_t h_stage_cap = 0;             // has the runtime pin those pages first, and with eight feeder threads at it at once
                                         // that call took 8 ms for some of them (profiles/r04/upload_trace_*.txt)
@@ -758,30 +755,6 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         fprintf(stderr, "done (popped %d)\n", dbg[0]);
         return 0;
     };
-    // What the chains of this range can be at most, where the host holds the list and the run is small enough for the choice of
-    // layout to hang on it (gact_policy.hpp layout_times): bases left and right of every seed hit, in tiles (gact.cpp:82-195: a
-    // tile advances a chain by at most `early` bases)
-    int est_tiles_max = 0;
-    long long est_tiles_sum = 0;
-    if (strands < 0 && !sl.h_cands.empty() && (size_t)first + (size_t)n <= sl.h_cands.size() && n <= e->grid_blocks * 32 && e->lin && e->split) {
-        const int64_t key[4] = {first, n, rc_from, e->sets_epoch};
-        if (memcmp(key, sl.est_key, sizeof key)) {
-            const int early = std::max(1, e->kp.early);
-            int mx = 0; long long sum = 0;
-            for (int k = first; k < first + n; k++) {
-                const gact_candidate &c = sl.h_cands[(size_t)k];
-                const SeqSet &qs = k >= rc_from ? qr : qf;
-                const int64_t rl = rs.h_offsets[(size_t)c.ref_id + 1] - rs.h_offsets[(size_t)c.ref_id];
-                const int64_t ql = qs.h_offsets[(size_t)c.query_id + 1] - qs.h_offsets[(size_t)c.query_id];
-                const int64_t left = std::min<int64_t>(c.ref_pos, c.query_pos), right = std::min<int64_t>(rl - c.ref_pos, ql - c.query_pos);
-                const int tiles = (int)((std::max<int64_t>(left, 0) + std::max<int64_t>(right, 0)) / early) + 2;
-                mx = std::max(mx, tiles); sum += tiles;
-            }
-            memcpy(sl.est_key, key, sizeof key);
-            sl.est_tiles_max = mx; sl.est_tiles_sum = sum;
-        }
-        est_tiles_max = sl.est_tiles_max; est_tiles_sum = sl.est_tiles_sum;
-    }
     // second_set: the pass files and pops its chains in the lane's second set of queues (the raw-byte pass behind the 2-bit
     // one on the same lane: the first set keeps its counts for the statistics, nothing is cleared between the passes).
     // WHAT the pass runs as -- kernels, grids, sequence -- is gact_policy::plan_pass's answer (gact_policy.hpp: a pure function
@@ -791,7 +764,6 @@ int launch_extend(gact_hip_engine *e, Slot &sl, int first, int n, int rc_from, i
         pol::Inputs in;
         in.count = count; in.raw = raw; in.listed = list != nullptr; in.second_set = second_set; in.shared_machine = shared_machine;
         in.own_lane = ln.stream == sl.stream; in.trace = trace; in.poison = e->poison != 0; in.lane_max_blocks = ln.max_blocks;
-        if (!list && !second_set) { in.est_tiles_max = est_tiles_max; in.est_tiles_sum = est_tiles_sum; }
         const pol::Plan plan = pol::plan_pass(policy_caps(e), in);
         const gact::SeqSetDev d_rs = rs.dev(raw), d_qf = qf.dev_or(raw, rs), d_qr = qr.dev_or(raw, rs);
         gact::ChainQueues cq = second_set ? second_queues(ln, sl) : queues(ln, sl);
@@ -2215,10 +2187,6 @@ int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, 
         e.coop = (flags & 8) ? 1 : (flags & 16) ? -1 : 0;
         gact_policy::Inputs in;
         in.count = count; in.raw = (flags & 1) != 0; in.shared_machine = (flags & 2) != 0;
-        // (bits 8-19: tiles of the longest chain the list can make, bits 20-31: mean tiles per chain -- what the host works out
-        //  of a list it holds; 0: unknown)
-        in.est_tiles_max = (flags >> 8) & 0xfff;
-        in.est_tiles_sum = (long long)((flags >> 20) & 0xfff) * count;
         t = gact_policy::describe(gact_policy::plan_pass(policy_caps(&e), in));
     }
     if (buf && cap > 0) {

@@ -48,33 +48,7 @@ struct Inputs {                  // of one pass
     bool listed = false;         // the seed launch takes a list (routing)
     bool second_set = false, shared_machine = false, own_lane = true, trace = false, poison = false;
     int lane_max_blocks = 0;     // the side lane's cap (0: none)
-    // what the host knows of the chains a list can make, when it holds the list (0: unknown): tiles of the longest, tiles of all
-    int est_tiles_max = 0;
-    long long est_tiles_sum = 0;
 };
-
-// The time model behind the choice of layout for a run of fewer chains than tile slots (all times in ms, rates in DP cells per
-// ms on 256 CUs, scaled by the CU count).  A launch lasts max(work / rate, longest chain x time per tile); measured on MI355X
-// (profiles/r05/sweep_policy_*.json, profiles/r04/ont_wide_blocks_per_cu.txt):
-//   wide layout, one block per CU   (one wave per SIMD: a lone wave issues every ~7 cycles)   3.3e9 cells/ms, 0.108 ms per tile
-//   wide layout, two blocks per CU                                                             5.0e9 cells/ms, 0.18  ms per tile
-//   split layout, three blocks per CU                                                          7.0e9 cells/ms, 0.30  ms per tile
-constexpr double kRateWide1 = 3.3e9, kRateWide2 = 5.0e9, kRateSplit = 7.0e9;
-constexpr double kTileMsWide1 = 0.108, kTileMsWide2 = 0.18, kTileMsSplit = 0.30;
-constexpr double kCellsPerTile = 320.0 * 320.0 * 0.93;
-struct LayoutTimes { double wide1, wide2, split; };
-inline LayoutTimes layout_times(const Caps &c, const Inputs &in)
-{
-    const double scale = c.cus / 256.0, cells = (double)in.est_tiles_sum * kCellsPerTile, lmax = (double)in.est_tiles_max;
-    // (more chains than a wide grid has tile slots: the slots are used in turns, the longest chain may start late)
-    const double rounds1 = std::max(1.0, (double)in.count / (c.cus * (double)kWideTilesPerBlock));
-    const double rounds2 = std::max(1.0, (double)in.count / (2.0 * c.cus * kWideTilesPerBlock));
-    LayoutTimes t;
-    t.wide1 = std::max(cells / (kRateWide1 * scale), lmax * kTileMsWide1 * std::min(rounds1, 1.5));
-    t.wide2 = std::max(cells / (kRateWide2 * scale), lmax * kTileMsWide2 * std::min(rounds2, 1.5));
-    t.split = std::max(cells / (kRateSplit * scale), lmax * kTileMsSplit);
-    return t;
-}
 
 enum class Seq { SingleInt32, Plain, Overlapped, CritLane };
 enum class SeedK { Int32, P16Raw, P16, P16Lin, P16Aff, P16AffNeg };
@@ -162,14 +136,6 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     // fewer chains than the narrow layouts have tile slots: the launch lasts as long as its longest chain, so chains are made
     // faster (32 lanes per tile pair, 4 tiles per wave) instead of more numerous -- unless the launch shares the machine
     p.wide = c20 && c.wide >= 0 && !lane_small && (c.wide > 0 || (count <= narrow_slots && (!in.shared_machine || !in.own_lane)));
-    // ... and unless the model says the split layout is faster all the same (many short chains: the all-wide launch is bound by
-    // what one wave per SIMD can issue, the split launch by chain length x 0.3 ms).  Only where the host holds the list.
-    int model_per_cu = 0;
-    if (p.wide && c.wide == 0 && in.est_tiles_max > 0 && c.lin && c.split && !in.raw && in.own_lane) {
-        const LayoutTimes t = layout_times(c, in);
-        if (t.split < 0.9 * std::min(t.wide1, t.wide2)) p.wide = false;
-        else model_per_cu = t.wide1 <= t.wide2 ? 1 : 2;
-    }
     p.lin = c.lin && !in.raw && (p.wide || c.split);
     p.aff = c.aff && !in.raw && !p.wide && c20;
     p.roles = c20 && c.roles && c.role_grid_blocks > 0 && p.lin && !p.wide && !(in.shared_machine && in.own_lane && c.team_when_shared);
@@ -192,7 +158,7 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     // two waves per SIMD, not three, for the wide launch (it lasts its longest chain); ONE block per CU once the linear-gap
     // wide launch has more chains than two blocks per CU hold (bound by throughput either way)
     const int slots_at_two = 2 * c.cus * kWideTilesPerBlock;
-    const int per_cu = c.wide_blocks_per_cu > 0 ? c.wide_blocks_per_cu : (p.lin && model_per_cu) ? model_per_cu : (p.lin && count > slots_at_two) ? 1 : 2;
+    const int per_cu = c.wide_blocks_per_cu > 0 ? c.wide_blocks_per_cu : (p.lin && count > slots_at_two) ? 1 : 2;
     const int wide_cap = std::min(p.lin ? c.wide_lin_grid_blocks : c.grid_blocks, per_cu * c.cus);
     const int wide_blocks = grid(ceil_div(count, kWideTilesPerBlock), wide_cap);
     // two waves per SIMD already saturate the DP code: a launch that shares the machine takes two blocks per CU of the three

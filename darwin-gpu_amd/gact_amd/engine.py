@@ -213,12 +213,9 @@ EXPORTS = ("gact_hip_create", "gact_hip_destroy", "gact_hip_last_error", "gact_h
            "gact_hip_comm_create", "gact_hip_comm_gather_lines", "gact_hip_comm_destroy", "gact_hip_options_describe", "gact_hip_plan_describe")
 
 
-def plan(count, flags=0, compute_units=256, tile_size=320, tile_overlap=120, scoring=(1, -1, -1, -1), threshold=35,
-         longest_tiles=0, mean_tiles=0):
+def plan(count, flags=0, compute_units=256, tile_size=320, tile_overlap=120, scoring=(1, -1, -1, -1), threshold=35):
     """the launch plan of gact_policy.hpp for one pass over `count` candidates (no device needed); flags: 1 raw bytes,
-    2 the launch shares the machine, 4 role launch on, 8 cooperative launch on; longest_tiles / mean_tiles: what the host
-    knows of the chains the list can make (0: nothing)"""
-    flags |= (min(int(longest_tiles), 4095) << 8) | (min(int(mean_tiles), 4095) << 20)
+    2 the launch shares the machine, 4 role launch on, 8 cooperative launch always, 16 never"""
     import json
     lib = load()
     lib.gact_hip_plan_describe.restype = C.c_int64

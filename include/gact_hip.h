@@ -323,8 +323,7 @@ int64_t gact_hip_options_describe(char *buf, int64_t cap);
 /* The launch plan -- sequence, kernels, grids -- that an engine of parameters p makes for one pass over `count` candidates on a
  * device of compute_units CUs (kernels at their nominal occupancy), as one JSON object.  flags: bit 0 = the read sets hold
  * bytes other than A/C/G/T, bit 1 = the launch shares the machine (other runs in flight), bit 2 = role launch on, bit 3 =
- * cooperative launch always, bit 4 = never (neither: where the policy takes it); bits 8-19 = tiles of the longest chain the list can make, bits 20-31 = mean tiles per chain (what the
- * engine works out of a list the host holds; 0: unknown -- the layout of a small run is then chosen by the count alone).
+ * cooperative launch always, bit 4 = never (neither: where the policy takes it).
  * The policy is a pure function (csrc/gact_policy.hpp); this entry exists so that it can be swept and tested without a
  * device.  Same buffer convention as gact_hip_options_describe. */
 int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, int32_t count, int32_t flags, char *buf, int64_t cap);

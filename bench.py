@@ -64,9 +64,15 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
             if b["kernel"] != kernel or b["kernel_cells"] != cells:
                 continue
             # (per launch: tools/pmc_summary.py averages over the launches of a pass since round 4)
-            sq = next(v for k, v in d["sq"].items() if k.startswith("extend"))
-            wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if k.startswith("extend") and "WRITE_SIZE" in v)
-            rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if k.startswith("extend") and "FETCH_SIZE" in v)
+            # the entry of THIS kernel in its plain form (the overlapped sequence's two-set variant, `..., true>`, is another kernel)
+            stem = kernel.replace(" ", "")[:-1]
+
+            def mine(k):
+                k = k.replace(" ", "")
+                return k.startswith(stem) and not k.endswith(",true>")
+            sq = next(v for k, v in d["sq"].items() if mine(k))
+            wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if mine(k) and "WRITE_SIZE" in v)
+            rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if mine(k) and "FETCH_SIZE" in v)
             out = {"source": os.path.relpath(path, here), "insts_valu": sq["SQ_INSTS_VALU"],
                    "gui_active": sq["GRBM_GUI_ACTIVE"], "write_kib": wr, "fetch_kib": rd,
                    "profiled_kernel_ms": b["kernel_ms"]}
@@ -233,6 +239,9 @@ def main():
     ap.add_argument("--no-reference-caller", action="store_true",
                     help="skip the reference's own unmodified darwin.cpp on the engine (a child process behind the timed region, N = 1)")
     ap.add_argument("--no-cabi-gather-check", action="store_true", help="N > 1: skip the second gather through the C-ABI's own RCCL path")
+    ap.add_argument("--scoring", default="1,-1,-1,-1",
+                    help="match,mismatch,gap_open,gap_extend of the headline engine (profiling runs of the affine kernels; the CPU baseline "
+                         "and parity gate follow it)")
     ap.add_argument("--strong-blocks-of", default="pacbio50mb",
                     help="the genome blocks the fixed strong-scaling job is made of (tests: a small one; config 4 is pacbio50mb)")
     ap.add_argument("--rehearse-on-one-device", action="store_true",
@@ -303,7 +312,8 @@ def main():
 
     global SIDE_SLOTS
     S = SIDE_SLOTS = max(1, args.slots)
-    eng = engine.Engine(device_id=local_rank, n_slots=S)
+    scoring = tuple(int(x) for x in args.scoring.split(","))
+    eng = engine.Engine(device_id=local_rank, n_slots=S, scoring=scoring)
     info = eng.device_info()
     eng.upload(engine.SET_REF, cat, offs)
     eng.upload(engine.SET_QUERY, cat, offs)
@@ -544,7 +554,7 @@ def main():
                       else "int16x2 (packed) main kernel, int32 seed kernel") if packed else "int32",
             "data": "synthetic",
             "config": {"workload": args.workload + "_self_overlap", "candidate_source": args.candidates, "tile_size": 320, "tile_overlap": 120,
-                       "scoring": "+1/-1/-1/-1", "reads": len(reads), "bases": int(offs[-1]),
+                       "scoring": "%+d/%+d/%+d/%+d" % scoring, "reads": len(reads), "bases": int(offs[-1]),
                        "candidates": int(len(cf_all) + len(cr_all)), "tiles": tot_tiles,
                        "cells_per_step": tot_cells, "parallelism": "candidates dealt round-robin over %d GPU(s)" % world,
                        # steps in flight: step k's records are fetched after step k+S-1 has been launched, each step on an engine
@@ -576,9 +586,10 @@ def main():
                                        "gen_seconds_per_rank": gen_all, "c_abi_rccl_gather": cpp_gather}
 
         if not args.no_cpu:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr)
-            out["cpu_baseline"]["reference"] = reference_baseline(reads, my_cf, rf)
-        if world == 1 and not use_dist and not args.no_others and args.workload == "ecoli10x":
+            out["cpu_baseline"], out["parity"] = cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr, scoring)
+            if scoring == (1, -1, -1, -1):
+                out["cpu_baseline"]["reference"] = reference_baseline(reads, my_cf, rf)
+        if world == 1 and not use_dist and not args.no_others and args.workload == "ecoli10x" and scoring == (1, -1, -1, -1):
             # the other single-GPU configurations of BASELINE.json, a few steps each, with their own parity gate
             eng.close()
             eng = None
@@ -874,7 +885,7 @@ def cpp_gather_check(eng, dist, torch, rank, world, n, gathered):
     return out
 
 
-def cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr):
+def cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr, scoring=(1, -1, -1, -1)):
     """The oracle (CPU restatement, kind "port") timed on this box's host cores on a
     bounded sample of the same candidates; the same sample is the parity gate."""
     import numpy as np
@@ -884,18 +895,18 @@ def cpu_baseline(args, cat, offs, rcat, my_cf, rf, my_cr, rr):
     # calibrate on a small slice, then size the sample for ~cpu_seconds
     probe = min(len(my_cf), 4 * threads)
     t = time.perf_counter()
-    _, cells = orc.gact_many(cat, offs, cat, offs, my_cf[:probe], complement=False, same_file=True, n_threads=threads)
+    _, cells = orc.gact_many(cat, offs, cat, offs, my_cf[:probe], complement=False, same_file=True, scoring=scoring, n_threads=threads)
     rate = cells / max(time.perf_counter() - t, 1e-6)
     mean_cells = max(cells / max(probe, 1), 1.0)
     n = int(min(len(my_cf), max(probe, args.cpu_seconds * rate / mean_cells)))
     t = time.perf_counter()
-    want, cells = orc.gact_many(cat, offs, cat, offs, my_cf[:n], complement=False, same_file=True, n_threads=threads)
+    want, cells = orc.gact_many(cat, offs, cat, offs, my_cf[:n], complement=False, same_file=True, scoring=scoring, n_threads=threads)
     dt = time.perf_counter() - t
     fields = ("ref_id", "query_id", "ab", "ae", "bb", "be", "score", "comp", "emitted",
               "first_tile_score", "n_tiles", "cells")
     ok = all(np.array_equal(rf[f][:n], want[f]) for f in fields)
     nr = min(len(my_cr), max(16, n // 8))
-    want_r, _ = orc.gact_many(cat, offs, rcat, offs, my_cr[:nr], complement=True, same_file=True, n_threads=threads)
+    want_r, _ = orc.gact_many(cat, offs, rcat, offs, my_cr[:nr], complement=True, same_file=True, scoring=scoring, n_threads=threads)
     ok = ok and all(np.array_equal(rr[f][:nr], want_r[f]) for f in fields)
     if not ok:
         raise SystemExit("bench.py: PARITY FAILURE between the HIP engine and the oracle on the sample")

@@ -73,7 +73,7 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
             sq = next(v for k, v in d["sq"].items() if mine(k))
             wr = next(v["WRITE_SIZE"] for k, v in d["write"].items() if mine(k) and "WRITE_SIZE" in v)
             rd = next(v["FETCH_SIZE"] for k, v in d["fetch"].items() if mine(k) and "FETCH_SIZE" in v)
-            out = {"source": os.path.relpath(path, here), "insts_valu": sq["SQ_INSTS_VALU"],
+            out = {"source": os.path.relpath(path, here), "insts_valu": sq["SQ_INSTS_VALU"], "active_inst_valu": sq.get("SQ_ACTIVE_INST_VALU"),
                    "gui_active": sq["GRBM_GUI_ACTIVE"], "write_kib": wr, "fetch_kib": rd,
                    "profiled_kernel_ms": b["kernel_ms"]}
             # the seed launch of the same passes (since round 5: its own roofline block)
@@ -473,7 +473,12 @@ def main():
             slots = pmc["insts_valu"] * 64.0 / main_cells
             # GRBM_GUI_ACTIVE counts over the 8 XCDs; 1024 SIMDs, 2 cycles per issue at the peak
             util = pmc["insts_valu"] * float(ISSUE_CYCLES) / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0)
+            # SQ_ACTIVE_INST_VALU counts, per wave, the quad-cycles (4 cycles) in which a VALU instruction of that wave is executing;
+            # summed over a SIMD's waves against the launch's cycles it says how much of the time the SIMD's vector pipe was taken
+            # -- the reading under which this launch is issue-bound, beside `valu_issue_utilisation`'s 2-cycle one
+            pipe = (pmc["active_inst_valu"] * 4.0 / (info["compute_units"] * 4 * pmc["gui_active"] / 8.0)) if pmc.get("active_inst_valu") else None
             executed = {"slots_per_cell": round(slots, 3), "valu_issue_utilisation": round(util, 4),
+                        "valu_pipe_occupancy": round(pipe, 4) if pipe else None,
                         "floor_over_executed": round(floor / slots, 4), "profiled_kernel_ms": pmc["profiled_kernel_ms"],
                         # counters cannot be read from inside this process: they are the committed rocprofv3 --pmc pass of this
                         # command; how far this run's kernel time is from the one they were taken at
@@ -502,6 +507,7 @@ def main():
             "mode": "one step at a time, seed launch then one main launch (%d steps behind the timed region; "
                     "%.3f ms per step, %.1f GCUPS)" % (n_roof, dt_roof * 1e3, my_cells / dt_roof / 1e9),
             "valu_issue_utilisation": executed["valu_issue_utilisation"] if executed else None,
+            "valu_pipe_occupancy": executed["valu_pipe_occupancy"] if executed else None,
             "executed_slots_per_cell": executed["slots_per_cell"] if executed else None,
             "achieved": round(achieved, 3), "peak": round(peak_slots, 3),
             "unit": "T lane-op slots/s (one lane of one wave64 VALU instruction; int16 pairs: two DP cells per slot)",

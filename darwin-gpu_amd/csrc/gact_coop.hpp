@@ -34,13 +34,6 @@ constexpr int kCoopBanks = 2;
 constexpr int kCoopJobs = (kBlockThreads / 64) * 8 * kCoopBanks;       // tile slots of a block x banks = the lanes of a walking wave
 static_assert(kCoopJobs == 64, "a walking wave serves every job of its block, one per lane");
 constexpr int kCoopCacheStride = 36;                                   // dwords of region cache per walking lane (32 used)
-// Bank 1 takes new chains only while the launch is still popping classes of at least this many tiles (chains are popped longest
-// first): a chain in a wave with two full banks advances once per TWO passes, and what is popped last decides when the launch
-// ends.  0: bank 1 pops to the end.
-#ifndef GACT_COOP_BANK1_MIN_TILES
-#define GACT_COOP_BANK1_MIN_TILES 24
-#endif
-constexpr int kCoopBank1LastBucket = GACT_COOP_BANK1_MIN_TILES > 0 ? kBuckets - 1 - length_class(GACT_COOP_BANK1_MIN_TILES) : kBuckets;
 
 struct CoopJob {                 // posting wave -> walking lane
     uint32_t ws_off;             // the tile's pointer words: byte offset of its (wsA | wsB) from ws_all
@@ -355,9 +348,9 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_coop_kernel(
             for (int guard = 0; guard < 3 && !pk.have; guard++) {
                 if (s.phase == 2) {
                     if (exhausted) break;
-                    // (bank 1 stops taking chains once the launch is down to its short classes: see kCoopBank1LastBucket; the
-                    //  rotated order of a launch with a critical lane beside it does not apply here)
-                    if (bank == 1 && my_bucket > kCoopBank1LastBucket && cq.leave_longest == 0) break;
+                    // (bank 1 takes chains to the end: closing it once the launch is down to its classes of fewer than 16 / 24 / 40
+                    //  tiles, so that the last chains run one bank per wave, cost 4 / 6 / 9 % with four runs in flight --
+                    //  8,223 -> 7,903 / 7,751 / 7,446 GCUPS on ecoli10x, profiles/r05/ab_coop_bank1_throttle.txt)
                     int cand = -1;
                     for (;;) {
                         const int *q_count = (TWO_SETS && second_set) ? cq.more_count : cq.bucket_count;

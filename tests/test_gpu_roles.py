@@ -85,7 +85,7 @@ def test_role_launch_equals_the_oracle_and_the_old_launch(monkeypatch, reads_and
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("n", [1, 2, 7, 31, 32, 33, 64, 65, 79, 80, 81, 160, 161, 1000])
+@pytest.mark.parametrize("n", [1, 7, 32, 33, 81, 161, 1000])
 def test_role_launch_at_every_list_size_around_a_bank(monkeypatch, reads_and_records, n, mode):
     """a block's bank holds 80 chains (role launch: 10 DP waves x 4 groups x 2 slots) or 32 (cooperative launch: 4 waves): empty
     banks, half-filled groups, one chain alone"""

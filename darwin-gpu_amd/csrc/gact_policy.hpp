@@ -33,7 +33,7 @@ struct Caps {                    // fixed at gact_hip_create
     int lane_small_factor = 3, lane_blocks = 0;
     int wide = 0;                // 0 auto, 1 always, -1 never
     int coop = 0;                // cooperative, batched walks (gact_coop.hpp): 0 auto -- where the launch is bound by throughput: it shares
-                                 // the machine, or has six chains and more per tile slot --, 1 always, -1 never
+                                 // the machine and has 1.5 chains and more per tile slot, or has six and more --, 1 always, -1 never
     int wide_blocks_per_cu = 0;
     int cus = 256;
     int grid_blocks = 0, seed_grid_blocks = 0, seed_lin_grid_blocks = 0, lin_grid_blocks = 0, aff_grid_blocks = 0,
@@ -142,7 +142,9 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     // cooperative walks: +5-8 % where throughput bounds the launch (ecoli10x with four runs in flight 7,681 -> 8,038 GCUPS,
     // pacbio50mb 7,833 -> 8,433 and its launch alone 140.1 -> 133.9 ms); a run of few chains per tile slot alone on the machine
     // ends with its longest chains and those advance half as fast with two banks per wave
-    const bool coop_auto = (in.shared_machine && in.own_lane) || count >= 6 * narrow_slots0;
+    // (... and so does a launch of few, long chains even when it shares the machine: the ONT shape, 14.5 k chains of 200-500 tiles,
+    //  with four runs in flight 5,055 GCUPS with two banks per wave against 6,890-7,470 with one)
+    const bool coop_auto = (in.shared_machine && in.own_lane && count >= narrow_slots0 + narrow_slots0 / 2) || count >= 6 * narrow_slots0;
     p.coop = c20 && (c.coop > 0 || (c.coop == 0 && coop_auto)) && p.lin && !p.wide && !p.roles && c.split &&
              !(in.shared_machine && in.own_lane && c.team_when_shared);
     const bool tg = c.tagged, raw = in.raw;

@@ -310,7 +310,7 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *                        events when a run is launched, which the first launches of a pipeline answer differently from run to run
  *   "coop"               the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback
  *                        walks (gact_hip_run_stats.role_waves == 2): 1 always, 0 never, 2 (default) where throughput bounds the
- *                        launch -- it shares the machine, or has six chains and more per resident tile slot
+ *                        launch -- it shares the machine and has 1.5 chains and more per resident tile slot, or has six and more
  *   "roles"              1: the split linear-gap main launch runs as DP waves + walker waves (gact_hip_run_stats.role_waves);
  *                        0 (default): one wave does everything for its tiles.  Same records; measured no faster
  * Every other switch of the library is read once, in gact_hip_create, from an environment variable; set_option names the

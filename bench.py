@@ -65,7 +65,7 @@ def pmc_lookup(workload_name, candidates, kernel, cells):
                 continue
             # (per launch: tools/pmc_summary.py averages over the launches of a pass since round 4)
             # the entry of THIS kernel in its plain form (the overlapped sequence's two-set variant, `..., true>`, is another kernel)
-            stem = kernel.replace(" ", "")[:-1]
+            stem = kernel.replace(" ", "").rstrip(">")      # (template arguments this line does not name may follow: <7,13,true>, ...)
 
             def mine(k):
                 k = k.replace(" ", "")

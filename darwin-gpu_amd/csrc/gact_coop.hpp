@@ -2,7 +2,7 @@
 //
 // What round 5 measured first (gact_roles.hpp, profiles/r05/): taking the walk off the DP waves -- dedicated walker waves, two
 // banks of tiles per DP wave -- does not make the launch faster.  The machine is bound by VALU issue (one wave64 instruction
-// per ~4 cycles and SIMD, two waves inside a pass saturate it; SQ_ACTIVE_INST_VALU = 93 % of the launch), so a wave that
+// per ~4 cycles and SIMD, two waves inside a pass saturate it), so a wave that
 // idles through its walk costs nothing the other waves of its SIMD do not make up, and a walker wave that runs all the time
 // with a few lanes at work executes as many instructions as the 8-lane walks it replaced (SQ_INSTS_VALU 1.608e10 against
 // 1.656e10).  What does help is FEWER instructions: the walk (align.cpp:185-230) is 213 dependent steps of ~45 VALU

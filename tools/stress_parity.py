@@ -27,7 +27,13 @@ MODES = [{}, {"GACT_HIP_FORCE_WIDE": "1"}, {"GACT_HIP_NO_WIDE": "1"}, {"GACT_HIP
          # round 4: the tagged affine pass of round 1 instead of the drifted one; a narrow band (second runs) and none
          {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_AFF": "1", "GACT_HIP_NO_LIN": "1"},
          {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_BAND": "24"}, {"GACT_HIP_BAND": "0"},
-         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_LIN": "1", "GACT_HIP_BAND": "24"}]
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_NO_LIN": "1", "GACT_HIP_BAND": "24"},
+         # round 5: two banks of tiles per wave with cooperative, batched walks (gact_coop.hpp), also with a narrow band's second
+         # runs; the role launch (gact_roles.hpp).  Both only where the split linear-gap launch would run
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_COOP": "1"}, {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_COOP": "1", "GACT_HIP_BAND": "24"},
+         {"GACT_HIP_NO_WIDE": "1", "GACT_HIP_ROLES": "1"}]
+if os.environ.get("STRESS_ROUND5_ONLY"):             # the three round-5 selections alone (and the automatic one)
+    MODES = MODES[:1] + MODES[-3:]
 ALL = sorted({k for m in MODES for k in m})
 t0 = time.time()
 total = 0
@@ -102,7 +108,8 @@ for it in range(n_cfg):
             else:
                 got = eng.extend(cands, complement=comp, same_file=True)
                 st = eng.last_run_stats()
-            key = ("big" if big else st["layout"] + ("-lin" if st["linear_gap"] else "-aff" if st.get("affine_drift") else "") + "/" + st["seed_layout"]) + (
+            key = ("big" if big else st["layout"] + ("-lin" if st["linear_gap"] else "-aff" if st.get("affine_drift") else "") +
+                   ("-coop" if st.get("coop_walks") else "-roles" if st.get("role_waves") else "") + "/" + st["seed_layout"]) + (
                 "+routed" if st["raw_candidates"] else "")
             layouts[key] = layouts.get(key, 0) + 1
             for f in FIELDS:

@@ -34,13 +34,6 @@ constexpr int kCoopBanks = 2;
 constexpr int kCoopJobs = (kBlockThreads / 64) * 8 * kCoopBanks;       // tile slots of a block x banks = the lanes of a walking wave
 static_assert(kCoopJobs == 64, "a walking wave serves every job of its block, one per lane");
 constexpr int kCoopCacheStride = 36;                                   // dwords of region cache per walking lane (32 used)
-// A wave that has just posted its walks and finds this many jobs of the block posted and unclaimed walks them at once, before
-// it goes on with its other bank -- so that the waves that posted them find their results done when they come back, instead of
-// waiting for whoever needs a result first (0: only the lazy rule of the header)
-#ifndef GACT_COOP_EAGER
-#define GACT_COOP_EAGER 0
-#endif
-constexpr int kCoopEagerJobs = GACT_COOP_EAGER;
 
 struct CoopJob {                 // posting wave -> walking lane
     uint32_t ws_off;             // the tile's pointer words: byte offset of its (wsA | wsB) from ws_all
@@ -488,20 +481,10 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_coop_kernel(
         if (w.gl == 0) bank_lds[group_in_block][bank][4] = (int)((wave_seq << 2) | 3u);      // what the bank's jobs read when done
         if ((threadIdx.x & 63) == 0) bank_lds[wave_in_block * kGroupsOfWave][0][5] = (int)wave_seq;
         wave_sync();
-        if (kCoopEagerJobs > 0) {
-            const uint32_t sj = __hip_atomic_load(&jstate[threadIdx.x & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_popcountll(__ballot((sj & 3u) == 1u)) >= kCoopEagerJobs) {
-                uint32_t got = 1;
-                if ((threadIdx.x & 63) == 0) got = atomicCAS(&walk_lock, 0u, 1u);
-                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                if (got == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    coop_walk_batch<L>(kp, ws_all, jobs, jstate, done, &stage_lds[0][0][0], cache_lds);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if ((threadIdx.x & 63) == 0) __hip_atomic_store(&walk_lock, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
+        // (walking eagerly -- a wave that has just posted walks at once when 16 / 24 / 32 / 48 jobs of the block are pending, so that
+        //  nobody waits for a result later -- takes the waiting out of the stamps, 24 % -> 9 % of a wave's time, and changes
+        //  nothing: pacbio50mb with four runs in flight 8,433 lazy against 8,211 / 8,347 / 8,362 / 8,406,
+        //  profiles/r05/ab_coop_eager_batches.txt.  The machine is bound by issue, not by waves that wait: DESIGN 3.13)
         GACT_STAMP(t_f);
         GACT_ACC(0, t_a, t_b); GACT_ACC(1, t_b, t_c); GACT_ACC(2, t_c, t_d); GACT_ACC(3, t_d, t_e);
         GACT_ACC(4, t_w0, t_a); GACT_ACC(5, t_e, t_f);

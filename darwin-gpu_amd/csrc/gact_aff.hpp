@@ -172,6 +172,39 @@ __device__ __forceinline__ uint32_t dp_pass_aff_split(const P16Consts &kc, const
         H2 = G[CT - 1]; Mo2 = Mb; D2 = Db;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     };
+    // a step in which region 2 is in front of its row 1 in every lane (t <= LAG; gact_lin.hpp 7.): region 1 alone
+    auto step_r1 = [&](const int t) {
+        const uint32_t w1 = ref16[t + 1];
+        Z1 += ev; Z2 += ev;
+        const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
+        const uint32_t Ml1 = (uint32_t)dpp_row_shr1((int)Mo1, (int)(Z1 - moev));
+        const uint32_t Dl1 = (uint32_t)dpp_row_shr1((int)D1, (int)floorv);
+        uint32_t P[C1], Mc[C1];
+#pragma unroll
+        for (int c = 0; c < C1; c++) P[c] = __builtin_amdgcn_perm(rb1b, rb1, qb[c]);
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C1; c++) {
+            const uint32_t hd = c == 0 ? Hdiag1 : G[c - 1];
+            Mc[c] = cb_neg ? (hd + P[c]) - cbv : add3u(hd, P[c], cbv);
+        }
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C1; c++) Iu[c] = pk_max3f(Mo[c], Iu[c], Z1);
+        GACT_SB();
+        Hdiag1 = Hl1;
+        uint32_t Ma = Ml1, Da = Dl1;
+#pragma unroll
+        for (int c = 0; c < C1; c++) {
+            const uint32_t Dma = pk_max(Ma, Da);
+            Da = Dma - ev;
+            G[c] = pk_max3f(Mc[c], Iu[c], Da);
+            Ma = Mc[c] - moev;
+            Mo[c] = Ma;
+        }
+        H1 = G[C1 - 1]; Mo1 = Ma; D1 = Da;
+        rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8);
+    };
 
     // ---- pointer phase: region 2 on scores times four; G'' and Mo'' tagged 3, I'' tagged 2, D'' tagged 1
     uint32_t Z24 = 0;
@@ -222,6 +255,56 @@ __device__ __forceinline__ uint32_t dp_pass_aff_split(const P16Consts &kc, const
         H2 = G[CT - 1]; Mo2 = Mb; D2 = Db;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8);
     };
+    // a step of the pointer phase in which region 1 is past its last row in every lane (t > T_end - LAG; gact_lin.hpp 7.):
+    // region 2 alone; H1, Mo1, D1 stay what lane 15 left at step T_end - LAG
+    auto step_tagged_r2 = [&](const int t) {
+        const uint32_t w2 = ref16[t + 1 - LAG];
+        Z24 += e4v;
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4v(H1, c3v)));
+        const uint32_t Ml2 = (uint32_t)dpp_row_shr1((int)Mo2, dpp_row_ror1((int)pk_mad4v(Mo1, c3v)));
+        const uint32_t Dl2 = (uint32_t)dpp_row_shr1((int)D2, dpp_row_ror1((int)pk_mad4v(D1, c1v)));
+        uint32_t P[C2], Mc[C2];
+#pragma unroll
+        for (int c = 0; c < C2; c++) P[c] = __builtin_amdgcn_perm(rb2b, rb2, qb[C1 + c]);
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C2; c++) {
+            const uint32_t hd = c == 0 ? Hdiag2 : G[C1 + c - 1];
+            Mc[c] = cb_neg ? (hd + P[c]) - cb4v : add3u(hd, P[c], cb4v);
+        }
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C2; c++) Iu[C1 + c] = pk_max3f(Mo[C1 + c], Iu[C1 + c], Z24);
+        GACT_SB();
+        Hdiag2 = Hl2;
+        uint32_t Mb = Ml2, Db = Dl2;
+        uint32_t tprev = 0, fprev = 0;
+#pragma unroll
+        for (int c = 0; c < C2; c++) {
+            const uint32_t Dp = pk_max(Mb, Db);
+            if (c > 0) { accO[c - 1] = pk_shl_add4(accO[c - 1], tprev); accF[c - 1] = pk_shl_add4(accF[c - 1], fprev); }
+            GACT_SB();
+            const uint32_t Ds = Dp - e4v;
+            fprev = Iu[C1 + c] + Dp;
+            GACT_SB();
+            Db = andn_or(Ds, c3v, c1v);
+            GACT_SB();
+            Iu[C1 + c] = andn_or(Iu[C1 + c], c3v, c2v);
+            GACT_SB();
+            const uint32_t Hp = pk_max3f(Mc[c], Iu[C1 + c], Db);
+            Mb = Mc[c] - moe4v;
+            Mo[C1 + c] = Mb;
+            fprev &= c3v;
+            GACT_SB();
+            G[C1 + c] = Hp | c3v;
+            tprev = Hp & c3v;
+            GACT_SB();
+        }
+        accO[C2 - 1] = pk_shl_add4(accO[C2 - 1], tprev);
+        accF[C2 - 1] = pk_shl_add4(accF[C2 - 1], fprev);
+        H2 = G[CT - 1]; Mo2 = Mb; D2 = Db;
+        rb2 = lut4(w2 & 0xffu); rb2b = lut4(w2 >> 8);
+    };
 #undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
@@ -268,18 +351,37 @@ __device__ __forceinline__ uint32_t dp_pass_aff_split(const P16Consts &kc, const
     };
 
     int t = 1;
+    // (gact_lin.hpp 7.: the first LAG steps without region 2 -- in front of its row 1 in every lane: H = I = the zero level, M =
+    //  what a mismatch on the row before makes it, D of no consequence --, the last LAG steps without region 1)
+    for (const int tP = imin(LAG, imin(tB - 1, T_end)); t <= tP; t++) step_r1(t);
+    if (t > 1) {
+        const uint32_t mo = (cb_neg ? (Z2 - ev) - cbv : (Z2 - ev) + cbv) - moev;
+#pragma unroll
+        for (int c = C1; c < CT; c++) { G[c] = Z2; Iu[c] = Z2; Mo[c] = mo; }
+        H2 = Z2; Hdiag2 = Z2; Mo2 = mo; D2 = floorv;
+        const uint32_t w2 = ref16[t - LAG];
+        rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
+    }
     for (; t < tB && t <= T_end; t++) step(t);
     const bool tagged = t <= T_end;
     if (tagged) enter_tagged();
     int k = 0;
-    while (t + 7 <= T_end) {                     // whole blocks of eight steps + flush (see dp_pass_lin_split)
+    while (t + 7 <= T_end && t <= T_end - LAG) { // whole blocks of eight steps + flush (see dp_pass_lin_split)
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
         flush(t - 8, t - 1, [](uint32_t w) { return w; });
         qA += QD * kWsRow;
         qB += QD * kWsRow;
     }
-    for (; t <= T_end; t++, k++) step_tagged(t);
+    while (t + 7 <= T_end) {
+        for (int s8 = 0; s8 < 8; s8++, t++) step_tagged_r2(t);
+        k += 8;
+        flush(t - 8, t - 1, [](uint32_t w) { return w; });
+        qA += QD * kWsRow;
+        qB += QD * kWsRow;
+    }
+    for (; t <= T_end - LAG; t++, k++) step_tagged(t);
+    for (; t <= T_end; t++, k++) step_tagged_r2(t);
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
         flush(t - (k & 7), t - 1, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); });

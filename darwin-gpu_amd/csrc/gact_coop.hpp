@@ -350,7 +350,12 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_coop_kernel(
                     if (exhausted) break;
                     // (bank 1 takes chains to the end: closing it once the launch is down to its classes of fewer than 16 / 24 / 40
                     //  tiles, so that the last chains run one bank per wave, cost 4 / 6 / 9 % with four runs in flight --
-                    //  8,223 -> 7,903 / 7,751 / 7,446 GCUPS on ecoli10x, profiles/r05/ab_coop_bank1_throttle.txt)
+                    //  8,223 -> 7,903 / 7,751 / 7,446 GCUPS on ecoli10x, profiles/r05/ab_coop_bank1_throttle.txt.  Nor does it make
+                    //  this launch the faster one for a run that has the machine to itself: "lean" waves -- no new chains into the
+                    //  other bank of a wave that holds a chain longer than 4..13 sixteenths of the longest one running -- bring
+                    //  ecoli10x alone from 37.7 ms to 34.1-35.6 where extend_p16_kernel takes 32.0, and cost pacbio50mb alone
+                    //  1-4 %: with twice the chains in flight the queues run dry at 21 ms and twice as many half-done chains are
+                    //  left to finish in waves that are no longer full, profiles/r05/ab_coop_lean_waves.txt)
                     int cand = -1;
                     for (;;) {
                         const int *q_count = (TWO_SETS && second_set) ? cq.more_count : cq.bucket_count;

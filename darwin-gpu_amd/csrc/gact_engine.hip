@@ -326,7 +326,7 @@ struct Combiner {
 
 struct gact_hip_engine {
     gact_hip_params params;
-    gact::KParams kp;
+    gact::KParams kp{};
     int C = 20;                 // columns per lane
     int big_cb = 0;             // tile_size > 512: the one-wave-per-tile kernels of gact_big.hpp, 16 or 32 columns per lane
     int big_blocks = 0;         //   and their grid (the workspace is one pointer matrix per wave)

@@ -245,6 +245,28 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         H1 = Ha; H2 = Hb;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
     };
+    // a step in which region 2 is in front of its row 1 in every lane (see 7. below): region 1 alone, region 2's zero level
+    auto step_r1 = [&](const int t) {
+        const uint32_t w1 = ref16[t + 1];
+        Z1 += gv; Z2 += gv;
+        const uint32_t Hl1 = (uint32_t)dpp_row_shr1((int)H1, (int)Z1);
+        uint32_t P[C1], U[C1];
+#pragma unroll
+        for (int c = 0; c < C1; c++) P[c] = __builtin_amdgcn_perm(rb1b, rb1, qb[c]);
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C1; c++) U[c] = (c == 0 ? Hdiag1 : G[c - 1]) + P[c];
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C1; c++) U[c] = GACT_LIN_MAX3 ? pk_max3f(U[c], Z1, G[c]) : pk_max(pk_max(U[c], Z1), G[c]);
+        GACT_SB();
+        Hdiag1 = Hl1;
+        uint32_t Ha = Hl1;
+#pragma unroll
+        for (int c = 0; c < C1; c++) { G[c] = pk_max(U[c], Ha - gv); Ha = G[c]; }
+        H1 = Ha;
+        rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8);
+    };
 
     // ---- pointer phase: region 2 on tagged scores; G = 4H + 2 there: H_up'' without an instruction, the diagonal gets
     //      its tag 3 from the look-up word (+1), the left neighbour its tag 1 from the gap subtraction (4|g| + 1), and
@@ -281,6 +303,41 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
         H1 = Ha; H2 = Hb;
         rb1 = lut(w1 & 0xffu); rb1b = lut(w1 >> 8); rb2 = lut4(w2 & 0xffu) + lut1v; rb2b = lut4(w2 >> 8) + lut1v;
     };
+    // a step of the pointer phase in which region 1 is past its last row in every lane (see 7. below): region 2 alone; H1
+    // stays what lane 15 left at step T_end - LAG
+    auto step_tagged_r2 = [&](const int t) {
+        const uint32_t w2 = ref16[t + 1 - LAG];
+        Z24 += g4v;
+        const uint32_t Hl2 = (uint32_t)dpp_row_shr1((int)H2, dpp_row_ror1((int)pk_mad4v(H1, c2v)));
+        uint32_t P[C2], U[C2];
+#pragma unroll
+        for (int c = 0; c < C2; c++) P[c] = __builtin_amdgcn_perm(rb2b, rb2, qb[C1 + c]);
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C2; c++) U[c] = (c == 0 ? Hdiag2 : G[C1 + c - 1]) + P[c];
+        GACT_SB();
+#pragma unroll
+        for (int c = 0; c < C2; c++) U[c] = GACT_LIN_MAX3 ? pk_max3f(U[c], Z24, G[C1 + c]) : pk_max(pk_max(U[c], Z24), G[C1 + c]);
+        GACT_SB();
+        Hdiag2 = Hl2;
+        uint32_t Hb = Hl2;
+        uint32_t tprev = 0;
+#pragma unroll
+        for (int c = 0; c < C2; c++) {
+            const uint32_t Db = Hb - dtv;
+            GACT_SB();
+            const uint32_t Hp = pk_max(U[c], Db);
+            if (c > 0) acc[c - 1] = pk_shl_add4(acc[c - 1], tprev);
+            GACT_SB();
+            G[C1 + c] = andn_or(Hp, c3v, c2v);
+            tprev = Hp & c3v;
+            GACT_SB();
+            Hb = G[C1 + c];
+        }
+        acc[C2 - 1] = pk_shl_add4(acc[C2 - 1], tprev);
+        H2 = Hb;
+        rb2 = lut4(w2 & 0xffu) + lut1v; rb2b = lut4(w2 >> 8) + lut1v;
+    };
 #undef GACT_SB
     auto enter_tagged = [&]() {
 #pragma unroll
@@ -292,6 +349,19 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     };
 
     int t = 1;
+    // 7. Region 2 runs LAG steps behind region 1 and every tile ends on the wave's last step: for the first LAG steps region 2
+    //    is in front of its row 1 in EVERY lane (its values are the zero level, whatever the reads hold), for the last LAG
+    //    steps region 1 is past its last row in every lane (nothing reads what it would compute: lane 0 of region 2 takes
+    //    lane 15's H of step T_end - LAG at step T_end - LAG + 1 and rows past R after that).  Those steps run without the
+    //    idle region's column slots: 16 x 65 + up to 16 x 37 of a pass's ~53 k instructions.
+    for (const int tP = imin(LAG, imin(tB - 1, T_end)); t <= tP; t++) step_r1(t);
+    if (t > 1) {
+#pragma unroll
+        for (int c = C1; c < CT; c++) G[c] = Z2;
+        H2 = Z2; Hdiag2 = Z2;
+        const uint32_t w2 = ref16[t - LAG];
+        rb2 = lut(w2 & 0xffu); rb2b = lut(w2 >> 8);
+    }
     for (; t < tB && t <= T_end; t++) step(t);
     const bool tagged = t <= T_end;
     if (tagged) enter_tagged();
@@ -313,14 +383,25 @@ __device__ __forceinline__ uint32_t dp_pass_lin_split(const P16Consts &kc, const
     // whole blocks of eight steps, each followed by its flush (an `if ((k & 7) == 7)` inside one loop is
     // if-converted by the compiler: the re-pairing v_perm of the flush would then run at every step)
     int k = 0;
-    while (t + 7 <= T_end) {
+    // (two loops one behind the other, not one loop with a branch inside: the two kinds of step keep their registers
+    //  differently, and a loop that holds both moves ~90 registers per block to reconcile them)
+    while (t + 7 <= T_end && t <= T_end - LAG) {
         for (int s8 = 0; s8 < 8; s8++, t++) step_tagged(t);
         k += 8;
         lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, bd.store(0, t - 8, t - 1), bd.store(1, t - 8, t - 1));
         qA += QD * kWsRow;
         qB += QD * kWsRow;
     }
-    for (; t <= T_end; t++, k++) step_tagged(t);
+    while (t + 7 <= T_end) {
+        for (int s8 = 0; s8 < 8; s8++, t++) step_tagged_r2(t);
+        k += 8;
+        lin_flush<NW, kGroup>(acc, qA, qB, [](uint32_t w) { return w; }, bd.store(0, t - 8, t - 1), bd.store(1, t - 8, t - 1));
+        qA += QD * kWsRow;
+        qB += QD * kWsRow;
+    }
+    // (what is left are the last seven steps at most: region 2 alone, unless the pointer phase began inside them)
+    for (; t <= T_end - LAG; t++, k++) step_tagged(t);
+    for (; t <= T_end; t++, k++) step_tagged_r2(t);
     if (k & 7) {
         const int sh = 2 * (8 - (k & 7));
         lin_flush<NW, kGroup>(acc, qA, qB, [sh](uint32_t w) { return ((w & 0xffffu) << sh & 0xffffu) | ((w >> 16) << sh << 16); },

@@ -256,6 +256,7 @@ static const OptionDef kOptions[] = {
     {"poison_ws", "GACT_HIP_POISON_WS", 'c', 'k', "<seed>: seeded garbage over the traceback workspace before every launch (tests)"},
     {"no_overlap", "GACT_HIP_NO_OVERLAP", 'c', 's', "seed launch, then one main launch, always; live: overlap_seed"},
     {"overlap_seed", nullptr, 'l', 's', "1 / 0: ordered, overlapped seeding of large runs on an idle engine"},
+    {"overlap_big", "GACT_HIP_OVERLAP_BIG", 'l', 's', "1 / 0 (default): ... also of runs of more than four chains per resident tile slot (seed launch A takes the longest eighth, B the rest beside main launch 1; +1.3 % on pacbio50mb alone)"},
     {"no_crit_lane", "GACT_HIP_NO_CRIT_LANE", 'c', 's', "no wide launch beside the split one for runs of 1-1.5 chains per tile slot"},
     {"crit_lane_always", "GACT_HIP_CRIT_LANE_ALWAYS", 'c', 's', "... also for runs of up to four chains per tile slot"},
     {"no_shared_hint", "GACT_HIP_NO_SHARED_HINT", 'c', 's', "a launch made while another slot runs may take the wide layout"},
@@ -360,6 +361,7 @@ struct gact_hip_engine {
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
     bool roles = false;         // GACT_HIP_ROLES=1 / set_option "roles": the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
     int role_grid_blocks = 0;   // ... and its persistent grid (blocks of kRoleThreads)
+    bool overlap_big = false;   // GACT_HIP_OVERLAP_BIG / set_option "overlap_big" (gact_policy.hpp Caps::overlap_big)
     int coop = 0;               // GACT_HIP_COOP / set_option "coop": two banks of tiles per wave and cooperative, batched walks (gact_coop.hpp):
                                 // 0 where throughput bounds the launch (gact_policy.hpp), 1 always, -1 never
     int aff_grid_blocks = 0;    // ... of the drifted affine split launch (two blocks per CU)
@@ -695,7 +697,7 @@ gact_policy::Caps policy_caps(const gact_hip_engine *e)
     gact_policy::Caps c;
     c.C = e->C; c.p16 = e->p16; c.seed16 = e->seed16; c.lin = e->lin; c.aff = e->aff; c.aff_seed = e->aff_seed; c.split = e->split; c.tagged = e->tagged;
     c.mismatch_below_extend = e->params.mismatch < e->params.gap_extend;
-    c.roles = e->roles; c.coop = (e->lin && e->split && e->C == 20) ? e->coop : -1; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
+    c.overlap_big = e->overlap_big; c.roles = e->roles; c.coop = (e->lin && e->split && e->C == 20) ? e->coop : -1; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
     c.lane_small = e->lane_small; c.lane_small_factor = e->lane_small_factor; c.lane_blocks = e->lane_blocks; c.team_when_shared = e->team_when_shared;
     c.wide = e->wide; c.wide_blocks_per_cu = e->wide_blocks_per_cu; c.cus = e->prop.multiProcessorCount;
     c.grid_blocks = e->grid_blocks; c.seed_grid_blocks = e->seed_grid_blocks; c.seed_lin_grid_blocks = e->seed_lin_grid_blocks;
@@ -1142,6 +1144,7 @@ static bool derive_kernel_flags(gact_hip_engine *e)
     e->shared_hint = opt_env("no_shared_hint") == nullptr;
     e->overlap_seed = opt_env("no_overlap") == nullptr;
     e->roles = opt_env("roles") != nullptr && atoi(opt_env("roles")) != 0;
+    if (const char *v = opt_env("overlap_big")) e->overlap_big = atoi(v) != 0;
     if (const char *v = opt_env("coop")) e->coop = atoi(v) == 1 ? 1 : atoi(v) == 0 ? -1 : 0;
     e->team_when_shared = opt_env("team_when_shared") != nullptr;
     e->static_prio = opt_env("static_prio") != nullptr;
@@ -2151,6 +2154,8 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
     } else if (n == "combine_window_us") {
         std::lock_guard<std::mutex> lk(e->cb.mu);
         e->cb.window_us = std::max(0, (int)value);
+    } else if (n == "overlap_big") {
+        e->overlap_big = value != 0;
     } else if (n == "coop") {
         if (value != 0 && !(e->lin && e->split && e->C == 20)) return fail(GACT_HIP_EINVAL, "set_option: this engine has no split linear-gap launch");
         e->coop = value == 1 ? 1 : value == 0 ? -1 : 0;
@@ -2168,7 +2173,8 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
 // The launch plan (gact_policy.hpp) an engine of these parameters makes for a pass of `count` candidates, on a machine of
 // `compute_units` CUs at the kernels' nominal occupancies (three blocks of four waves per CU for the main and the linear-gap
 // seed launches, two for the other seed launches, one role block): no engine, no device.  flags: bit 0 the sets hold bytes
-// other than A/C/G/T (raw-byte kernels), bit 1 the launch shares the machine, bit 2 the role launch is switched on.
+// other than A/C/G/T (raw-byte kernels), bit 1 the launch shares the machine, bit 2 the role launch is switched on, bit 3 / 4
+// cooperative walks always / never, bit 5 overlapped seeding also beyond four chains per tile slot ("overlap_big" 1).
 int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, int32_t count, int32_t flags, char *buf, int64_t cap)
 {
     if (!p || compute_units < 1 || count < 0) return fail(GACT_HIP_EINVAL, "plan_describe: bad arguments");
@@ -2185,6 +2191,7 @@ int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, 
         e.role_grid_blocks = (e.lin && e.split && e.C == 20) ? compute_units : 0;
         if (flags & 4) e.roles = e.role_grid_blocks > 0;
         e.coop = (flags & 8) ? 1 : (flags & 16) ? -1 : 0;
+        if (flags & 32) e.overlap_big = true;
         gact_policy::Inputs in;
         in.count = count; in.raw = (flags & 1) != 0; in.shared_machine = (flags & 2) != 0;
         t = gact_policy::describe(gact_policy::plan_pass(policy_caps(&e), in));

@@ -9,7 +9,10 @@
 //   count <= S (and the engine idle)     all wide: every chain resident from the start, the launch lasts its longest chain
 //   S < count < 1.5 S                     split launch + critical lane (a wide launch on a third of the blocks, longest chains)
 //   1.5 S <= count <= 4 S                 ordered, overlapped seeding: seed A | main 1 (2/3) || seed B -> main 2 (1/3)
-//   count > 4 S                           seed launch, then one main launch on the whole machine
+//   count > 4 S                           seed launch, then one main launch on the whole machine; from 6 S on in the cooperative
+//                                         layout.  (overlap_big: overlapped seeding here too, seed A = the longest eighth of the
+//                                         list.  pacbio50mb alone 141.1 -> 139.3 ms, +1.3 %: not the default -- seed launch B has
+//                                         a third of the machine, and where chains are short it, not the DP, bounds the run)
 // A launch that shares the machine (other slots running, or the caller says it keeps runs in flight) takes the plain
 // sequence in the throughput layout on two thirds of the blocks.
 #pragma once
@@ -30,6 +33,7 @@ struct Caps {                    // fixed at gact_hip_create
     bool p16 = false, seed16 = false, lin = false, aff = false, aff_seed = true, split = false, tagged = false;
     bool mismatch_below_extend = false;
     bool roles = false, overlap_seed = true, crit_lane = true, crit_lane_always = false, lane_small = false, team_when_shared = false;
+    bool overlap_big = false;    // overlapped seeding also for runs of more than four chains per tile slot (see plan_pass)
     int lane_small_factor = 3, lane_blocks = 0;
     int wide = 0;                // 0 auto, 1 always, -1 never
     int coop = 0;                // cooperative, batched walks (gact_coop.hpp): 0 auto -- where the launch is bound by throughput: it shares
@@ -86,23 +90,26 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     // ---- ordered, overlapped seeding
     if (c20 && c.overlap_seed && !in.raw && !in.listed && !in.trace && !in.poison && c.seed16 && c.lin && c.split && c.wide <= 0 &&
         !in.second_set && !in.shared_machine && in.own_lane && in.lane_max_blocks == 0 && count >= narrow_slots0 + narrow_slots0 / 2 &&
-        count <= 4 * narrow_slots0 && c.lin_grid_blocks >= 3) {
+        (count <= 4 * narrow_slots0 || c.overlap_big) && c.lin_grid_blocks >= 3) {
         p.seq = Seq::Overlapped;
         p.seed = SeedK::P16Lin;
         p.lin = true;
         p.roles = c.roles && c.role_grid_blocks > 0;
         const int main1 = c.lin_grid_blocks * 2 / 3, main2 = c.lin_grid_blocks - main1;
         const int role1 = c.role_grid_blocks * 2 / 3, role2 = c.role_grid_blocks - role1;
-        p.coop = !p.roles && c.coop > 0;          // (a run this size is one at a time on an idle engine: two banks per wave double a
-                                                  //  chain's time per tile, and the launch ends with its longest chains -- ecoli10x
-                                                  //  37.3 ms against 30.6, profiles/r05/ab_coop_vs_old_first.txt)
+        // (a run of up to four chains per tile slot, one at a time on an idle engine: two banks per wave double a chain's time per
+        //  tile, and the launch ends with its longest chains -- ecoli10x 37.3 ms against 30.6, profiles/r05/ab_coop_vs_old_first.txt)
+        p.coop = !p.roles && (c.coop > 0 || (c.coop == 0 && count >= 6 * narrow_slots0));
         p.main = p.roles ? MainK::RolesLin : p.coop ? MainK::CoopLin : MainK::SplitLin;
         p.main_blocks = p.roles ? role1 : main1;
         p.main2_blocks = p.roles ? role2 : main2;
         p.ws_split = p.roles ? (size_t)role1 * c.role_ws_words_per_block : p.coop ? (size_t)main1 * c.coop_ws_words_per_block : ws_words_for(c, main1);
         // seed launch B runs on a third of the machine, and until it has ended main launch 1 gets no new chains: it is given
         // what it can seed in a few milliseconds, two candidates per resident tile slot; a larger run seeds the rest in A
-        p.nA = std::max(std::min(count, main1 * kNarrowTilesPerBlock), count - 2 * narrow_slots0);
+        // (overlap_big, a run of more than four per slot: seed A takes two per slot or the longest eighth of the list, seed B the
+        //  rest while main launch 1 works on A's -- B seeds ~9 candidates in the time main launch 1 finishes one chain of
+        //  pacbio50mb's, and a wave of main launch 1 that finds nothing for 2 ms gives up)
+        p.nA = count > 4 * narrow_slots0 ? std::max(2 * narrow_slots0, count / 8) : std::max(std::min(count, main1 * kNarrowTilesPerBlock), count - 2 * narrow_slots0);
         auto seed_blocks_for = [&](int cnt, int cap) { return std::max(1, std::min(ceil_div(ceil_div(cnt, 2 * kGroupsPerWave), 4), cap)); };
         p.seed_blocks = seed_blocks_for(p.nA, c.seed_lin_grid_blocks);
         p.seedB_blocks = seed_blocks_for(count - p.nA, main2);

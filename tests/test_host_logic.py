@@ -69,6 +69,11 @@ def test_launch_policy_operating_points():
         p = _plan(n)
         assert (p["sequence"], p["main_kernel"]) == (seq, main), (n, p)
         assert p["seed_kernel"] == "seed_p16<lin>" and p["linear"] and not p["roles"]
+        # "overlap_big" 1 (flag 32): overlapped seeding beyond four chains per slot too, seed launch A = the longest eighth
+        q = _plan(n, flags=32)
+        assert q["sequence"] == ("overlapped-seeding" if n > 4 * S else seq) and q["main_kernel"] == main, (n, q)
+        if n > 4 * S:
+            assert q["n_a"] == max(2 * S, n // 8) and q["main_blocks"] == 512 and q["second_main_blocks"] == 256
     # a launch that shares the machine: the throughput layout -- two banks per wave, cooperative walks -- on two thirds of the
     # blocks, no second stream, whatever the count; "coop" 0 keeps the one-wave-does-all launch
     for n in (100, S, 2 * S, 10 * S):
@@ -101,7 +106,7 @@ def test_launch_policy_is_sane_over_a_sweep_of_counts():
     prev = None
     n = 1
     while n <= 3_000_000:
-        for flags in (0, 2, 4):
+        for flags in (0, 2, 4, 32):
             p = _plan(n, flags=flags)
             assert 1 <= p["seed_blocks"] <= 3 * cus and 1 <= p["main_blocks"] <= 3 * cus and p["second_main_blocks"] <= cus
             per_block = 16 if p["wide"] else 160 if p["roles"] else 64 if p["coop"] else 32
@@ -117,6 +122,8 @@ def test_launch_policy_is_sane_over_a_sweep_of_counts():
                 assert slots >= min(n, floor_slots), (n, flags, p)
             if p["sequence"] in ("overlapped-seeding", "seed+main+critical-lane"):
                 second = p["second_main_blocks"] * (16 if p["critical_lane"] else per_block) * 13760
+                if p["coop"] and not p["critical_lane"]:     # (a cooperative block lays out its two banks' region-2 words only)
+                    second = p["second_main_blocks"] * (p["ws_split_words"] // p["main_blocks"])
                 assert 0 < p["ws_split_words"] and (p["roles"] or p["ws_split_words"] + second <= ws_total), (n, p)
             if p["sequence"] == "overlapped-seeding":
                 assert 0 < p["n_a"] <= n and p["seed_b_blocks"] >= 1

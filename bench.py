@@ -160,6 +160,8 @@ def main_kernel_name(st):
         name = {"extend_p16_kernel<UniformLayout<20>>": "extend_p16_kernel<UniformLayout<20,16,true>>",
                 "extend_p16_kernel<SplitLayout<7,13>>": "extend_p16_kernel<SplitLayout<7,13,true>>",
                 "extend_p16_kernel<WideLayout>": "extend_p16_kernel<WideLayoutTagged>"}[name]
+    if st.get("critical_lane"):         # a wide launch beside it holds the longest chains (two kernels: no single PMC line to quote)
+        name += " + extend_p16_kernel<WideLayoutLin> (critical lane)"
     return name
 
 

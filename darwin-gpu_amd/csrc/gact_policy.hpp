@@ -33,6 +33,9 @@ struct Caps {                    // fixed at gact_hip_create
     bool p16 = false, seed16 = false, lin = false, aff = false, aff_seed = true, split = false, tagged = false;
     bool mismatch_below_extend = false;
     bool roles = false, overlap_seed = true, crit_lane = true, crit_lane_always = false, lane_small = false, team_when_shared = false;
+    int lone_lane = 48;          // a run of S/2 ... S chains alone on the machine runs as ONE block per CU of two kinds: that many wide blocks
+                                 // for its longest chains, split blocks on the other CUs (see plan_pass); < 0: the split blocks without
+                                 // the look-ahead walker; 0: all wide
     bool overlap_big = false;    // overlapped seeding also for runs of more than four chains per tile slot (see plan_pass)
     int lane_small_factor = 3, lane_blocks = 0;
     int wide = 0;                // 0 auto, 1 always, -1 never
@@ -189,6 +192,26 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
             p.leave_longest = lane_blocks * kWideTilesPerBlock;
             return p;
         }
+    }
+    // ---- one wave per SIMD everywhere, two layouts (lone_lane).  The all-wide launch of a run with more chains than two wide blocks
+    //      per CU hold runs one block per CU (a wave alone on its SIMD issues every 7 cycles, and the launch is bound by
+    //      that).  The split layout executes fewer instructions per tile (7.9 k against 9.1 k), the wide one fewer per tile of ONE
+    //      chain (0.108 ms against 0.185 alone on a SIMD): so the longest chains -- the ones a split wave could not finish in time --
+    //      go to `lone` wide blocks and everything else to split blocks, every block alone on its CU (256 blocks on 256 CUs; the
+    //      look-ahead walker pays for a wave that has its SIMD to itself).  ONT shape alone 78.6 -> 67.4 ms; 16 k ... 24 k chains of
+    //      5 ... 100 kb reads +13 ... +23 %; below S/2 chains the all-wide launch is faster (profiles/r05/lone_lane_*.txt)
+    const int lone = c.lone_lane < 0 ? -c.lone_lane : c.lone_lane;
+    if (c20 && lone > 0 && lone < c.cus && p.wide && p.lin && per_cu == 1 && count > narrow_slots0 / 2 && c.wide == 0 && c.split && !raw && !in.trace &&
+        !in.second_set && !in.shared_machine && in.own_lane && in.lane_max_blocks == 0 && lone <= c.wide_lin_grid_blocks && c.cus - lone <= c.lin_grid_blocks) {
+        p.seq = Seq::CritLane;
+        p.lane = true;
+        p.wide = false; p.roles = false; p.coop = false;
+        p.main = c.lone_lane > 0 ? MainK::SplitLinTeam : MainK::SplitLin;
+        p.main2_blocks = lone;
+        p.main_blocks = c.cus - lone;
+        p.ws_split = ws_words_for(c, c.cus - lone);
+        p.leave_longest = lone * kWideTilesPerBlock;
+        return p;
     }
     p.seq = Seq::Plain;
     if (p.roles) {

@@ -340,6 +340,43 @@ def test_the_critical_lane_changes_no_record(monkeypatch):
     eng.close()
 
 
+def test_the_lone_mix_changes_no_record():
+    """A run of S/2 ... S chains alone on the machine (S = 24,576 resident tile slots) runs one block per CU of two kinds: 48
+    wide blocks for its longest chains, split blocks with the look-ahead walker (SplitLayoutLinTeam) on the other CUs
+    (gact_policy.hpp lone_lane).  Ranges of ecoli10x of that size: the same records as all wide ("lone_lane" 0), as without
+    the look-ahead walker (-48), with other lane sizes, and as the same candidates inside the whole list's run."""
+    from conftest import workload_block
+    from gact_amd import engine
+    blk = workload_block("ecoli10x")
+    cands = np.concatenate([blk.cf, blk.cr])
+    nf = len(blk.cf)
+    eng = engine.Engine()
+    _load(eng, blk.rs)
+    eng.candidates_upload(cands)
+    eng.candidates_run_mixed(len(cands), rc_from=nf)
+    whole = eng.candidates_fetch(len(cands)).copy()
+    rng = np.random.default_rng(505)
+    for lane in (48, 0, -48, 16, 96, 48):
+        eng.set_option("lone_lane", lane)
+        for _ in range(3):
+            n = int(rng.integers(12300, 24576))
+            first = int(rng.integers(0, len(cands) - n))
+            eng.candidates_run_mixed(n, rc_from=nf, first=first)
+            got = eng.candidates_fetch(len(cands))[first:first + n]
+            st = eng.last_run_stats()
+            assert st["critical_lane"] == (lane != 0) and st["layout"] == ("packed16-split" if lane else "packed16-wide"), (lane, n, st)
+            assert got.tobytes() == whole[first:first + n].tobytes(), (lane, first, n)
+    # not below S/2 chains, not for a run that shares the machine
+    eng.candidates_run_mixed(12000, rc_from=nf, first=30000)
+    assert eng.candidates_fetch(len(cands))[30000:42000].tobytes() == whole[30000:42000].tobytes()
+    assert eng.last_run_stats()["layout"] == "packed16-wide" and not eng.last_run_stats()["critical_lane"]
+    eng.set_option("runs_in_flight", 1)
+    eng.candidates_run_mixed(20000, rc_from=nf, first=30000)
+    assert eng.candidates_fetch(len(cands))[30000:50000].tobytes() == whole[30000:50000].tobytes()
+    assert not eng.last_run_stats()["critical_lane"]
+    eng.close()
+
+
 @pytest.mark.parametrize("scoring", [(1, -1, -1, -1), (2, -3, -5, -2), (3, -2, -4, -2)], ids=["linear", "affine", "affine-mismatch-is-extend"])
 @pytest.mark.parametrize("band", [24, 0])
 def test_a_narrow_band_runs_tiles_again_and_changes_nothing(monkeypatch, oracle, band, scoring):

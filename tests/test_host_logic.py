@@ -61,7 +61,8 @@ def _plan(count, **kw):
 def test_launch_policy_operating_points():
     """the four sequences of a pass, at the thresholds DESIGN 3.5 names (S = 24,576 resident tile slots on 256 CUs)"""
     S = 3 * 256 * 32
-    for n, seq, main in ((1, "seed+main", "WideLayoutLin"), (S, "seed+main", "WideLayoutLin"),
+    for n, seq, main in ((1, "seed+main", "WideLayoutLin"), (S // 2, "seed+main", "WideLayoutLin"),
+                         (S // 2 + 1, "seed+main+critical-lane", "SplitLayoutLinTeam"), (S, "seed+main+critical-lane", "SplitLayoutLinTeam"),
                          (S + 1, "seed+main+critical-lane", "SplitLayoutLin"), (S + S // 2 - 1, "seed+main+critical-lane", "SplitLayoutLin"),
                          (S + S // 2, "overlapped-seeding", "SplitLayoutLin"), (4 * S, "overlapped-seeding", "SplitLayoutLin"),
                          (4 * S + 1, "seed+main", "SplitLayoutLin"), (6 * S - 1, "seed+main", "SplitLayoutLin"),
@@ -72,6 +73,8 @@ def test_launch_policy_operating_points():
         # "overlap_big" 1 (flag 32): overlapped seeding beyond four chains per slot too, seed launch A = the longest eighth
         q = _plan(n, flags=32)
         assert q["sequence"] == ("overlapped-seeding" if n > 4 * S else seq) and q["main_kernel"] == main, (n, q)
+        if main == "SplitLayoutLinTeam":    # the lone mix: 256 blocks on 256 CUs, 48 of them wide, holding the 768 longest chains
+            assert p["main_blocks"] + p["second_main_blocks"] == 256 and p["second_main_blocks"] == 48 and p["leave_longest"] == 768
         if n > 4 * S:
             assert q["n_a"] == max(2 * S, n // 8) and q["main_blocks"] == 512 and q["second_main_blocks"] == 256
     # a launch that shares the machine: the throughput layout -- two banks per wave, cooperative walks -- on two thirds of the
@@ -119,6 +122,8 @@ def test_launch_policy_is_sane_over_a_sweep_of_counts():
             if not p["wide"]:
                 #  (the critical lane's third of the blocks holds 16 tiles a block, not 32)
                 floor_slots = cus * 80 if p["roles"] else S * 2 // 3 if flags == 2 else S * 5 // 6 if p["critical_lane"] else S
+                if p["main_kernel"] == "SplitLayoutLinTeam":     # (the lone mix is ONE block per CU by design)
+                    floor_slots = (cus - 48) * 32 + 48 * 16
                 assert slots >= min(n, floor_slots), (n, flags, p)
             if p["sequence"] in ("overlapped-seeding", "seed+main+critical-lane"):
                 second = p["second_main_blocks"] * (16 if p["critical_lane"] else per_block) * 13760

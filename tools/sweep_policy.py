@@ -24,6 +24,7 @@ ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "sweep_policy.
 ap.add_argument("--lengths", default="2000,5000,10000,30000,100000")
 ap.add_argument("--counts", default="1000,3000,10000,20000,30000,45000,65000,100000,200000,400000,1000000")
 ap.add_argument("--max-cells", type=float, default=6e12, help="points whose estimated cells exceed this are skipped")
+ap.add_argument("--set", default="", help="live options for the engine, e.g. lone_lane=0,overlap_big=1 (gact_hip_set_option)")
 args = ap.parse_args()
 lengths = [int(x) for x in args.lengths.split(",")]
 counts = [int(x) for x in args.counts.split(",")]
@@ -39,6 +40,8 @@ for L in lengths:
     base_rc = np.concatenate([np.zeros(len(cf), bool), np.ones(len(cr), bool)])
     cat, offs = rs.concat(); rcat, roffs = rs.concat(rc=True)
     eng = engine.Engine()
+    for kv in filter(None, args.set.split(",")):
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     eng.upload(engine.SET_REF, cat, offs); eng.upload(engine.SET_QUERY, cat, offs); eng.upload(engine.SET_QUERY_RC, rcat, roffs)
     # cells of one pass over the base list
     eng.candidates_upload(base)

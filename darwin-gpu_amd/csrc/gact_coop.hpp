@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_coop_kernel(
                     //  1-4 %: with twice the chains in flight the queues run dry at 21 ms and twice as many half-done chains are
                     //  left to finish in waves that are no longer full, profiles/r05/ab_coop_lean_waves.txt; closing bank 1 to the
                     //  classes of fewer than 8 ... 48 tiles for such a run: ecoli10x 38.0 -> 32.5-36.3 ms, still behind; pacbio50mb
-                    //  alone has no tail to cut -- queues dry at 132.9 of 135.4 ms --, ab_single_run_bank1_close_and_stagger.txt)
+                    //  alone has no tail to cut -- queues dry at 132.9 of 135.4 ms --, single_run_vs_in_flight_experiments.txt)
                     int cand = -1;
                     for (;;) {
                         const int *q_count = (TWO_SETS && second_set) ? cq.more_count : cq.bucket_count;

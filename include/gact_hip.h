@@ -311,6 +311,13 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *   "coop"               the split linear-gap main launch with two banks of tiles per wave and cooperative, batched traceback
  *                        walks (gact_hip_run_stats.role_waves == 2): 1 always, 0 never, 2 (default) where throughput bounds the
  *                        launch -- it shares the machine and has 1.5 chains and more per resident tile slot, or has six and more
+ *   "lone_lane"          a run of half as many to as many chains as there are resident tile slots, alone on the machine, runs as ONE
+ *                        block per CU of two kinds: value (default 48) wide blocks for its longest chains, split blocks with the
+ *                        look-ahead walker on the other CUs (value < 0: without it); 0: all wide.  (gact_hip_run_stats: layout
+ *                        split, critical_lane 1)
+ *   "overlap_big"        1: ordered, overlapped seeding also for runs of more than four chains per resident tile slot (seed launch A
+ *                        takes the longest eighth of the list, B the rest beside main launch 1); 0 (default): seed launch, then one
+ *                        main launch
  *   "roles"              1: the split linear-gap main launch runs as DP waves + walker waves (gact_hip_run_stats.role_waves);
  *                        0 (default): one wave does everything for its tiles.  Same records; measured no faster
  * Every other switch of the library is read once, in gact_hip_create, from an environment variable; set_option names the

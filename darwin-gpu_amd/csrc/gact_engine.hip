@@ -256,6 +256,7 @@ static const OptionDef kOptions[] = {
     {"poison_ws", "GACT_HIP_POISON_WS", 'c', 'k', "<seed>: seeded garbage over the traceback workspace before every launch (tests)"},
     {"no_overlap", "GACT_HIP_NO_OVERLAP", 'c', 's', "seed launch, then one main launch, always; live: overlap_seed"},
     {"overlap_seed", nullptr, 'l', 's', "1 / 0: ordered, overlapped seeding of large runs on an idle engine"},
+    {"shared_twelfths", "GACT_HIP_SHARED_TWELFTHS", 'l', 's', "<n>: a linear-gap main launch that shares the machine and has more chains than two thirds of the resident tile slots hold takes n twelfths of the resident blocks (default 6)"},
     {"lone_lane", "GACT_HIP_LONE_LANE", 'l', 's', "<n>: a run of half as many to as many chains as there are resident tile slots, alone on the machine, runs as one block per CU of two kinds: n wide blocks for its longest chains (default 48), split blocks with the look-ahead walker on the other CUs (-n: without it); 0: all wide"},
     {"overlap_big", "GACT_HIP_OVERLAP_BIG", 'l', 's', "1 / 0 (default): ... also of runs of more than four chains per resident tile slot (seed launch A takes the longest eighth, B the rest beside main launch 1; +1.3 % on pacbio50mb alone)"},
     {"no_crit_lane", "GACT_HIP_NO_CRIT_LANE", 'c', 's', "no wide launch beside the split one for runs of 1-1.5 chains per tile slot"},
@@ -362,6 +363,7 @@ struct gact_hip_engine {
     int lin_grid_blocks = 0;    // persistent grid of the linear-gap split launch (its own occupancy)
     bool roles = false;         // GACT_HIP_ROLES=1 / set_option "roles": the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
     int role_grid_blocks = 0;   // ... and its persistent grid (blocks of kRoleThreads)
+    int shared_twelfths = 6;    // GACT_HIP_SHARED_TWELFTHS / set_option "shared_twelfths" (gact_policy.hpp Caps::shared_twelfths)
     int lone_lane = 48;         // GACT_HIP_LONE_LANE / set_option "lone_lane" (gact_policy.hpp Caps::lone_lane)
     bool overlap_big = false;   // GACT_HIP_OVERLAP_BIG / set_option "overlap_big" (gact_policy.hpp Caps::overlap_big)
     int coop = 0;               // GACT_HIP_COOP / set_option "coop": two banks of tiles per wave and cooperative, batched walks (gact_coop.hpp):
@@ -699,7 +701,7 @@ gact_policy::Caps policy_caps(const gact_hip_engine *e)
     gact_policy::Caps c;
     c.C = e->C; c.p16 = e->p16; c.seed16 = e->seed16; c.lin = e->lin; c.aff = e->aff; c.aff_seed = e->aff_seed; c.split = e->split; c.tagged = e->tagged;
     c.mismatch_below_extend = e->params.mismatch < e->params.gap_extend;
-    c.lone_lane = e->lone_lane; c.overlap_big = e->overlap_big; c.roles = e->roles; c.coop = (e->lin && e->split && e->C == 20) ? e->coop : -1; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
+    c.shared_twelfths = e->shared_twelfths; c.lone_lane = e->lone_lane; c.overlap_big = e->overlap_big; c.roles = e->roles; c.coop = (e->lin && e->split && e->C == 20) ? e->coop : -1; c.overlap_seed = e->overlap_seed; c.crit_lane = e->crit_lane; c.crit_lane_always = e->crit_lane_always;
     c.lane_small = e->lane_small; c.lane_small_factor = e->lane_small_factor; c.lane_blocks = e->lane_blocks; c.team_when_shared = e->team_when_shared;
     c.wide = e->wide; c.wide_blocks_per_cu = e->wide_blocks_per_cu; c.cus = e->prop.multiProcessorCount;
     c.grid_blocks = e->grid_blocks; c.seed_grid_blocks = e->seed_grid_blocks; c.seed_lin_grid_blocks = e->seed_lin_grid_blocks;
@@ -1147,6 +1149,7 @@ static bool derive_kernel_flags(gact_hip_engine *e)
     e->overlap_seed = opt_env("no_overlap") == nullptr;
     e->roles = opt_env("roles") != nullptr && atoi(opt_env("roles")) != 0;
     if (const char *v = opt_env("overlap_big")) e->overlap_big = atoi(v) != 0;
+    if (const char *v = opt_env("shared_twelfths")) e->shared_twelfths = std::max(1, std::min(atoi(v), 12));
     if (const char *v = opt_env("lone_lane")) e->lone_lane = std::max(-255, std::min(atoi(v), 255));
     if (const char *v = opt_env("coop")) e->coop = atoi(v) == 1 ? 1 : atoi(v) == 0 ? -1 : 0;
     e->team_when_shared = opt_env("team_when_shared") != nullptr;
@@ -2159,6 +2162,8 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
         e->cb.window_us = std::max(0, (int)value);
     } else if (n == "overlap_big") {
         e->overlap_big = value != 0;
+    } else if (n == "shared_twelfths") {
+        e->shared_twelfths = std::max(1, std::min((int)value, 12));
     } else if (n == "lone_lane") {
         e->lone_lane = std::max(-255, std::min((int)value, 255));
     } else if (n == "coop") {

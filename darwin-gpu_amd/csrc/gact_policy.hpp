@@ -14,7 +14,7 @@
 //                                         list.  pacbio50mb alone 141.1 -> 139.3 ms, +1.3 %: not the default -- seed launch B has
 //                                         a third of the machine, and where chains are short it, not the DP, bounds the run)
 // A launch that shares the machine (other slots running, or the caller says it keeps runs in flight) takes the plain
-// sequence in the throughput layout on two thirds of the blocks.
+// sequence in the throughput layout on two thirds of the blocks -- on half of them when its list is longer than those hold.
 #pragma once
 
 #include <algorithm>
@@ -33,6 +33,7 @@ struct Caps {                    // fixed at gact_hip_create
     bool p16 = false, seed16 = false, lin = false, aff = false, aff_seed = true, split = false, tagged = false;
     bool mismatch_below_extend = false;
     bool roles = false, overlap_seed = true, crit_lane = true, crit_lane_always = false, lane_small = false, team_when_shared = false;
+    int shared_twelfths = 6;     // a linear-gap launch that shares the machine takes this many twelfths of the resident blocks (see lin_cap)
     int lone_lane = 48;          // a run of S/2 ... S chains alone on the machine runs as ONE block per CU of two kinds: that many wide blocks
                                  // for its longest chains, split blocks on the other CUs (see plan_pass); < 0: the split blocks without
                                  // the look-ahead walker; 0: all wide
@@ -174,7 +175,12 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     const int wide_cap = std::min(p.lin ? c.wide_lin_grid_blocks : c.grid_blocks, per_cu * c.cus);
     const int wide_blocks = grid(ceil_div(count, kWideTilesPerBlock), wide_cap);
     // two waves per SIMD already saturate the DP code: a launch that shares the machine takes two blocks per CU of the three
-    const int lin_cap = (in.shared_machine && in.own_lane) ? std::max(1, c.lin_grid_blocks * 2 / 3) : c.lin_grid_blocks;
+    // (... and HALF of them once the list is longer than two thirds hold: four runs in flight then put through 1.8 % more on
+    //  ecoli10x, 0.5 % on pacbio50mb -- 6, 7, 8 twelfths, four interleaved runs each, profiles/r05/ab_shared_share_of_blocks.txt; a
+    //  list that fits -- the ONT shape's 14.5 k long chains -- keeps a tile slot per chain)
+    const int two_thirds = std::max(1, c.lin_grid_blocks * 2 / 3);
+    const int lin_cap = !(in.shared_machine && in.own_lane) ? c.lin_grid_blocks
+                        : count <= two_thirds * kNarrowTilesPerBlock ? two_thirds : std::max(1, c.lin_grid_blocks * c.shared_twelfths / 12);
     const int lin_blocks = grid(ceil_div(groups_needed, 4), lin_cap);
     const int main_blocks_now = p.aff ? grid(ceil_div(groups_needed, 4), c.aff_grid_blocks) : main_blocks;
     // ---- the critical lane beside ONE split main launch

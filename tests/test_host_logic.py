@@ -83,6 +83,8 @@ def test_launch_policy_operating_points():
         p = _plan(n, flags=2)
         want = "coop<SplitLayoutLin>" if n >= S + S // 2 else "SplitLayoutLin"      # (few, long chains: one bank per wave)
         assert p["sequence"] == "seed+main" and p["main_kernel"] == want and p["main_blocks"] <= 512, (n, p)
+        # (two thirds of the blocks while every chain gets a tile slot there, half of them beyond)
+        assert p["main_blocks"] == (min(-(-n // 32), 512) if n <= 512 * 32 else 384), (n, p)
         assert _plan(n, flags=2 | 16)["main_kernel"] == "SplitLayoutLin"
     assert _plan(2 * S, flags=8)["main_kernel"] == "coop<SplitLayoutLin>" and _plan(2 * S, flags=8)["sequence"] == "overlapped-seeding"
     # the role launch: one block of twelve waves per CU, in the same sequences
@@ -121,7 +123,7 @@ def test_launch_policy_is_sane_over_a_sweep_of_counts():
             #  ... and a launch that shares the machine two blocks per CU of the three)
             if not p["wide"]:
                 #  (the critical lane's third of the blocks holds 16 tiles a block, not 32)
-                floor_slots = cus * 80 if p["roles"] else S * 2 // 3 if flags == 2 else S * 5 // 6 if p["critical_lane"] else S
+                floor_slots = cus * 80 if p["roles"] else (S * 2 // 3 if n <= S * 2 // 3 else S // 2) if flags == 2 else S * 5 // 6 if p["critical_lane"] else S
                 if p["main_kernel"] == "SplitLayoutLinTeam":     # (the lone mix is ONE block per CU by design)
                     floor_slots = (cus - 48) * 32 + 48 * 16
                 assert slots >= min(n, floor_slots), (n, flags, p)

@@ -753,6 +753,23 @@ __device__ __forceinline__ int longest_running(const ChainQueues &cq, int mine, 
     return ref;
 }
 
+// ... every kRankEvery-th tile only, waves taking turns: longest_running is an agent-scope atomic max, a store and two loads on ONE
+// line of memory; with every wave of a launch doing that at every tile (3,072 waves, a tile per 0.3 ms: ~40 operations per
+// microsecond on one address) the waves queued for it -- pacbio50mb alone 139.7 ms with, 118.4 without (round 5,
+// profiles/r05/ranking_atomics.txt; with several launches in flight each has its own ring, which is most of why runs in flight
+// looked faster than one run alone).  The rank is a slow quantity: a slice of the ring is 1.3 ms.
+constexpr int kRankEvery = 16;
+__device__ __forceinline__ int ranked_longest(const ChainQueues &cq, const KParams &kp, int wave_longest, int &turn, int &cached)
+{
+    if (kp.prio_bases[0] != 0) return 0;                      // fixed thresholds or none: nobody reads the ring
+    if ((turn & (kRankEvery - 1)) == 0) {
+        cached = __builtin_amdgcn_readfirstlane(longest_running(cq, wave_longest, (threadIdx.x & 63) == 0));
+        if (turn == 0) turn = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (kRankEvery - 1));      // (from here on the waves take turns)
+    }
+    turn++;
+    return imax(cached, wave_longest);
+}
+
 // bases this chain still has to cover, roughly (each tile advances ~early of them)
 __device__ __forceinline__ int chain_remaining(const ChainState &s)
 {

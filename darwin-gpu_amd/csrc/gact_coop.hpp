@@ -242,6 +242,8 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_coop_kernel(
     bool second_set = false;
     constexpr bool one_set = !TWO_SETS;
     int idle_polls = 0;
+    // (the ranking against the longest chain running: every kRankEvery-th tile, the waves of a launch taking turns; the first tile always)
+    int rank_turn = 0, rank_cached = 0;
     int bank = 0;
     __builtin_amdgcn_s_setprio(3);
 #ifdef GACT_STAMPS
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(kBlockThreads, 3) void extend_coop_kernel(
         GACT_STAMP(t_c);
 
         const int wave_longest = wave_max_groups<LANES>(longest);
-        const int ref_longest = __builtin_amdgcn_readfirstlane(longest_running(cq, wave_longest, (threadIdx.x & 63) == 0));
+        const int ref_longest = ranked_longest(cq, kp, wave_longest, rank_turn, rank_cached);
         const bool rank_hi = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] >> 8) * ref_longest
                                                    : wave_longest > kp.prio_bases[1];
         const bool rank_mid = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] & 255) * ref_longest

@@ -845,6 +845,8 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
     bool second_set = false;
     constexpr bool one_set = !TWO_SETS;              // nothing to switch to
     int idle_polls = 0;
+    // (the ranking against the longest chain running: every kRankEvery-th tile, the waves of a launch taking turns; the first tile always)
+    int rank_turn = 0, rank_cached = 0;
     __builtin_amdgcn_s_setprio(3);
 #ifdef GACT_STAMPS
     unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -960,7 +962,7 @@ __global__ __launch_bounds__(kBlockThreads, L::kBlocksPerCu) void extend_p16_ker
         // ... and among the DP passes, the waves that carry the longest chains go first: when there are
         // fewer chains than tile slots the launch lasts as long as its longest chain
         const int wave_longest = wave_max_groups<LANES>(longest);
-        const int ref_longest = __builtin_amdgcn_readfirstlane(longest_running(cq, wave_longest, (threadIdx.x & 63) == 0));
+        const int ref_longest = ranked_longest(cq, kp, wave_longest, rank_turn, rank_cached);
         // ranking mode (prio_bases[0] == 0): prio_bases[1] = thresholds in sixteenths of the longest, hi << 8 | mid
         const bool rank_hi = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] >> 8) * ref_longest
                                                    : wave_longest > kp.prio_bases[1];

@@ -279,6 +279,8 @@ __global__ __launch_bounds__(kRoleThreads, 3) void extend_roles_kernel(
     bool second_set = false;
     constexpr bool one_set = !TWO_SETS;
     int idle_polls = 0;
+    // (the ranking against the longest chain running: every kRankEvery-th tile, the waves of a launch taking turns; the first tile always)
+    int rank_turn = 0, rank_cached = 0;
     // What a bank's pass leaves behind for its consume step lives in LDS, like the chain states: the DP loop owns the
     // register file.  bank_lds[group][bank] = {R, Q of slot A, of slot B (0: no tile), sequence number of the jobs in flight
     // (0: none)}; the wave's job counter sits beside it.
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(kRoleThreads, 3) void extend_roles_kernel(
         GACT_STAMP(t_c);
 
         const int wave_longest = wave_max_groups<LANES>(longest);
-        const int ref_longest = __builtin_amdgcn_readfirstlane(longest_running(cq, wave_longest, (threadIdx.x & 63) == 0));
+        const int ref_longest = ranked_longest(cq, kp, wave_longest, rank_turn, rank_cached);
         const bool rank_hi = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] >> 8) * ref_longest
                                                    : wave_longest > kp.prio_bases[1];
         const bool rank_mid = kp.prio_bases[0] == 0 ? 16 * wave_longest > (kp.prio_bases[1] & 255) * ref_longest

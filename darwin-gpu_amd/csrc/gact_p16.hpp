@@ -1119,6 +1119,9 @@ __global__ __launch_bounds__(kBlockThreads, MODE == 1 ? 3 : 2) void seed_p16_ker
     if (w.gl < kSlots) { st[w.gl].phase = 2; st[w.gl].cand = -1; st[w.gl].comp = 0; }
     wave_sync();
     bool exhausted = false;
+    // (DP cells of the candidates this group is done with: added to the launch's counter once, when the wave leaves -- an atomic
+    //  per candidate on the line the candidates are popped from made every pop wait, profiles/r05/ranking_atomics.txt)
+    unsigned long long cells_done = 0;
     __builtin_amdgcn_s_setprio(3);
 
     for (;;) {
@@ -1138,8 +1141,7 @@ __global__ __launch_bounds__(kBlockThreads, MODE == 1 ? 3 : 2) void seed_p16_ker
                                   qfwd, qrc)) { exhausted = true; break; }
                 }
                 pk = chain_pick(s, kp, same_file, out, w.gl == 0);
-                if (!pk.have && w.gl == 0)
-                    atomicAdd(cq.seed_cells, (unsigned long long)s.cells);     // finished inside the seed launch
+                if (!pk.have && w.gl == 0) cells_done += (unsigned long long)s.cells;     // finished inside the seed launch
             }
             have[h] = pk.have;
             pt.R[h] = pk.R; pt.Q[h] = pk.Q; pt.reverse[h] = pk.reverse;
@@ -1224,7 +1226,7 @@ __global__ __launch_bounds__(kBlockThreads, MODE == 1 ? 3 : 2) void seed_p16_ker
                         const int b = chain_bucket(s, kp);
                         const int slot = atomicAdd(&cq.bucket_count[b], 1);
                         cq.live[(size_t)b * cq.live_stride + slot] = s.cand;
-                        atomicAdd(cq.seed_cells, (unsigned long long)s.cells);
+                        cells_done += (unsigned long long)s.cells;
                     }
                     s.phase = 2;
                 }
@@ -1234,6 +1236,7 @@ __global__ __launch_bounds__(kBlockThreads, MODE == 1 ? 3 : 2) void seed_p16_ker
             wave_sync();
         }
     }
+    if (w.gl == 0 && cells_done) atomicAdd(cq.seed_cells, cells_done);
 }
 
 }  // namespace gact

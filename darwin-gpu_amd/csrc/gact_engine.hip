@@ -257,7 +257,7 @@ static const OptionDef kOptions[] = {
     {"no_overlap", "GACT_HIP_NO_OVERLAP", 'c', 's', "seed launch, then one main launch, always; live: overlap_seed"},
     {"overlap_seed", nullptr, 'l', 's', "1 / 0: ordered, overlapped seeding of large runs on an idle engine"},
     {"shared_twelfths", "GACT_HIP_SHARED_TWELFTHS", 'l', 's', "<n>: a linear-gap main launch that shares the machine and has more chains than two thirds of the resident tile slots hold takes n twelfths of the resident blocks (default 6)"},
-    {"lone_lane", "GACT_HIP_LONE_LANE", 'l', 's', "<n>: a run of half as many to as many chains as there are resident tile slots, alone on the machine, runs as one block per CU of two kinds: n wide blocks for its longest chains (default 48), split blocks with the look-ahead walker on the other CUs (-n: without it); 0: all wide"},
+    {"lone_lane", "GACT_HIP_LONE_LANE", 'l', 's', "<n>: a run of half as many to as many chains as there are resident tile slots, alone on the machine, runs as one block per CU of two kinds: n wide blocks for its longest chains, split blocks with the look-ahead walker on the other CUs (-n: without it); 0 (default): all wide, two blocks per CU"},
     {"overlap_big", "GACT_HIP_OVERLAP_BIG", 'l', 's', "1 / 0 (default): ... also of runs of more than four chains per resident tile slot (seed launch A takes the longest eighth, B the rest beside main launch 1; +1.3 % on pacbio50mb alone)"},
     {"no_crit_lane", "GACT_HIP_NO_CRIT_LANE", 'c', 's', "no wide launch beside the split one for runs of 1-1.5 chains per tile slot"},
     {"crit_lane_always", "GACT_HIP_CRIT_LANE_ALWAYS", 'c', 's', "... also for runs of up to four chains per tile slot"},
@@ -364,7 +364,7 @@ struct gact_hip_engine {
     bool roles = false;         // GACT_HIP_ROLES=1 / set_option "roles": the split linear-gap main launch runs with DP waves and walker waves (gact_roles.hpp)
     int role_grid_blocks = 0;   // ... and its persistent grid (blocks of kRoleThreads)
     int shared_twelfths = 6;    // GACT_HIP_SHARED_TWELFTHS / set_option "shared_twelfths" (gact_policy.hpp Caps::shared_twelfths)
-    int lone_lane = 48;         // GACT_HIP_LONE_LANE / set_option "lone_lane" (gact_policy.hpp Caps::lone_lane)
+    int lone_lane = 0;          // GACT_HIP_LONE_LANE / set_option "lone_lane" (gact_policy.hpp Caps::lone_lane)
     bool overlap_big = false;   // GACT_HIP_OVERLAP_BIG / set_option "overlap_big" (gact_policy.hpp Caps::overlap_big)
     int coop = 0;               // GACT_HIP_COOP / set_option "coop": two banks of tiles per wave and cooperative, batched walks (gact_coop.hpp):
                                 // 0 where throughput bounds the launch (gact_policy.hpp), 1 always, -1 never
@@ -2184,7 +2184,8 @@ int gact_hip_set_option(gact_hip_engine *e, const char *name, int32_t value)
 // `compute_units` CUs at the kernels' nominal occupancies (three blocks of four waves per CU for the main and the linear-gap
 // seed launches, two for the other seed launches, one role block): no engine, no device.  flags: bit 0 the sets hold bytes
 // other than A/C/G/T (raw-byte kernels), bit 1 the launch shares the machine, bit 2 the role launch is switched on, bit 3 / 4
-// cooperative walks always / never, bit 5 overlapped seeding also beyond four chains per tile slot ("overlap_big" 1).
+// cooperative walks always / never, bit 5 overlapped seeding also beyond four chains per tile slot ("overlap_big" 1), bit 6 the lone
+// mix ("lone_lane" 48).
 int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, int32_t count, int32_t flags, char *buf, int64_t cap)
 {
     if (!p || compute_units < 1 || count < 0) return fail(GACT_HIP_EINVAL, "plan_describe: bad arguments");
@@ -2202,6 +2203,7 @@ int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, 
         if (flags & 4) e.roles = e.role_grid_blocks > 0;
         e.coop = (flags & 8) ? 1 : (flags & 16) ? -1 : 0;
         if (flags & 32) e.overlap_big = true;
+        if (flags & 64) e.lone_lane = 48;
         gact_policy::Inputs in;
         in.count = count; in.raw = (flags & 1) != 0; in.shared_machine = (flags & 2) != 0;
         t = gact_policy::describe(gact_policy::plan_pass(policy_caps(&e), in));

@@ -34,9 +34,9 @@ struct Caps {                    // fixed at gact_hip_create
     bool mismatch_below_extend = false;
     bool roles = false, overlap_seed = true, crit_lane = true, crit_lane_always = false, lane_small = false, team_when_shared = false;
     int shared_twelfths = 6;     // a linear-gap launch that shares the machine takes this many twelfths of the resident blocks (see lin_cap)
-    int lone_lane = 48;          // a run of S/2 ... S chains alone on the machine runs as ONE block per CU of two kinds: that many wide blocks
-                                 // for its longest chains, split blocks on the other CUs (see plan_pass); < 0: the split blocks without
-                                 // the look-ahead walker; 0: all wide
+    int lone_lane = 0;           // n != 0: a run of S/2 ... S chains alone on the machine runs as ONE block per CU of
+                                 // two kinds: |n| wide blocks for its longest chains, split blocks on the other CUs (see plan_pass); n < 0: the
+                                 // split blocks without the look-ahead walker; 0 (default): all wide
     bool overlap_big = false;    // overlapped seeding also for runs of more than four chains per tile slot (see plan_pass)
     int lane_small_factor = 3, lane_blocks = 0;
     int wide = 0;                // 0 auto, 1 always, -1 never
@@ -171,7 +171,12 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     // two waves per SIMD, not three, for the wide launch (it lasts its longest chain); ONE block per CU once the linear-gap
     // wide launch has more chains than two blocks per CU hold (bound by throughput either way)
     const int slots_at_two = 2 * c.cus * kWideTilesPerBlock;
-    const int per_cu = c.wide_blocks_per_cu > 0 ? c.wide_blocks_per_cu : (p.lin && count > slots_at_two) ? 1 : 2;
+    // (round 5, after the ranking's atomics were taken off every tile -- gact_chain.hpp ranked_longest --: TWO.  "One block per CU
+    //  once the launch has more chains than two hold" was a measurement of that contention, which grew with the number of waves:
+    //  ONT shape alone 72.9 / 58.8 / 74.4 ms at one / two / three blocks per CU now, 77.7 / 79.8 / 110 then; 13 k ... 24 k chains
+    //  of 5 ... 100 kb reads 20-35 % faster at two than at one, profiles/r05/layout_calibration_after_the_ranking_fix.txt)
+    const int per_cu = c.wide_blocks_per_cu > 0 ? c.wide_blocks_per_cu : 2;
+    (void)slots_at_two;
     const int wide_cap = std::min(p.lin ? c.wide_lin_grid_blocks : c.grid_blocks, per_cu * c.cus);
     const int wide_blocks = grid(ceil_div(count, kWideTilesPerBlock), wide_cap);
     // two waves per SIMD already saturate the DP code: a launch that shares the machine takes two blocks per CU of the three
@@ -205,9 +210,12 @@ inline Plan plan_pass(const Caps &c, const Inputs &in)
     //      chain (0.108 ms against 0.185 alone on a SIMD): so the longest chains -- the ones a split wave could not finish in time --
     //      go to `lone` wide blocks and everything else to split blocks, every block alone on its CU (256 blocks on 256 CUs; the
     //      look-ahead walker pays for a wave that has its SIMD to itself).  ONT shape alone 78.6 -> 67.4 ms; 16 k ... 24 k chains of
-    //      5 ... 100 kb reads +13 ... +23 %; below S/2 chains the all-wide launch is faster (profiles/r05/lone_lane_*.txt)
+    //      5 ... 100 kb reads +13 ... +23 %; below S/2 chains the all-wide launch is faster (profiles/r05/lone_lane_*.txt).
+    //      NOT the default any more: all of that was measured against an all-wide launch at ONE block per CU, which is what the
+    //      ranking's contention made the best wide launch; at two blocks per CU the all-wide launch beats the mix (ONT 58.8 against
+    //      66.9 ms).  Kept as an option ("lone_lane")
     const int lone = c.lone_lane < 0 ? -c.lone_lane : c.lone_lane;
-    if (c20 && lone > 0 && lone < c.cus && p.wide && p.lin && per_cu == 1 && count > narrow_slots0 / 2 && c.wide == 0 && c.split && !raw && !in.trace &&
+    if (c20 && lone > 0 && lone < c.cus && p.wide && p.lin && count > narrow_slots0 / 2 && c.wide == 0 && c.split && !raw && !in.trace &&
         !in.second_set && !in.shared_machine && in.own_lane && in.lane_max_blocks == 0 && lone <= c.wide_lin_grid_blocks && c.cus - lone <= c.lin_grid_blocks) {
         p.seq = Seq::CritLane;
         p.lane = true;

@@ -61,8 +61,7 @@ def _plan(count, **kw):
 def test_launch_policy_operating_points():
     """the four sequences of a pass, at the thresholds DESIGN 3.5 names (S = 24,576 resident tile slots on 256 CUs)"""
     S = 3 * 256 * 32
-    for n, seq, main in ((1, "seed+main", "WideLayoutLin"), (S // 2, "seed+main", "WideLayoutLin"),
-                         (S // 2 + 1, "seed+main+critical-lane", "SplitLayoutLinTeam"), (S, "seed+main+critical-lane", "SplitLayoutLinTeam"),
+    for n, seq, main in ((1, "seed+main", "WideLayoutLin"), (S // 2, "seed+main", "WideLayoutLin"), (S, "seed+main", "WideLayoutLin"),
                          (S + 1, "seed+main+critical-lane", "SplitLayoutLin"), (S + S // 2 - 1, "seed+main+critical-lane", "SplitLayoutLin"),
                          (S + S // 2, "overlapped-seeding", "SplitLayoutLin"), (4 * S, "overlapped-seeding", "SplitLayoutLin"),
                          (4 * S + 1, "seed+main", "SplitLayoutLin"), (6 * S - 1, "seed+main", "SplitLayoutLin"),
@@ -73,8 +72,15 @@ def test_launch_policy_operating_points():
         # "overlap_big" 1 (flag 32): overlapped seeding beyond four chains per slot too, seed launch A = the longest eighth
         q = _plan(n, flags=32)
         assert q["sequence"] == ("overlapped-seeding" if n > 4 * S else seq) and q["main_kernel"] == main, (n, q)
-        if main == "SplitLayoutLinTeam":    # the lone mix: 256 blocks on 256 CUs, 48 of them wide, holding the 768 longest chains
-            assert p["main_blocks"] + p["second_main_blocks"] == 256 and p["second_main_blocks"] == 48 and p["leave_longest"] == 768
+        if main == "WideLayoutLin":         # two wide blocks per CU at most (16 tiles each)
+            assert p["main_blocks"] == min(-(-n // 16), 512), (n, p)
+        # "lone_lane" 48 (flag 64): S/2 ... S chains as the lone mix -- 256 blocks on 256 CUs, 48 of them wide, holding the 768 longest
+        m = _plan(n, flags=64)
+        if S // 2 < n <= S:
+            assert (m["sequence"], m["main_kernel"]) == ("seed+main+critical-lane", "SplitLayoutLinTeam"), (n, m)
+            assert m["main_blocks"] + m["second_main_blocks"] == 256 and m["second_main_blocks"] == 48 and m["leave_longest"] == 768
+        else:
+            assert (m["sequence"], m["main_kernel"]) == (seq, main), (n, m)
         if n > 4 * S:
             assert q["n_a"] == max(2 * S, n // 8) and q["main_blocks"] == 512 and q["second_main_blocks"] == 256
     # a launch that shares the machine: the throughput layout -- two banks per wave, cooperative walks -- on two thirds of the
@@ -111,7 +117,7 @@ def test_launch_policy_is_sane_over_a_sweep_of_counts():
     prev = None
     n = 1
     while n <= 3_000_000:
-        for flags in (0, 2, 4, 32):
+        for flags in (0, 2, 4, 32, 64):
             p = _plan(n, flags=flags)
             assert 1 <= p["seed_blocks"] <= 3 * cus and 1 <= p["main_blocks"] <= 3 * cus and p["second_main_blocks"] <= cus
             per_block = 16 if p["wide"] else 160 if p["roles"] else 64 if p["coop"] else 32

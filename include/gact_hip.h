@@ -312,9 +312,11 @@ int gact_hip_prepare(gact_hip_engine *e, int32_t expected_candidates);
  *                        walks (gact_hip_run_stats.role_waves == 2): 1 always, 0 never, 2 (default) where throughput bounds the
  *                        launch -- it shares the machine and has 1.5 chains and more per resident tile slot, or has six and more
  *   "lone_lane"          a run of half as many to as many chains as there are resident tile slots, alone on the machine, runs as ONE
- *                        block per CU of two kinds: value (default 48) wide blocks for its longest chains, split blocks with the
- *                        look-ahead walker on the other CUs (value < 0: without it); 0: all wide.  (gact_hip_run_stats: layout
- *                        split, critical_lane 1)
+ *                        block per CU of two kinds: value wide blocks (e.g. 48) for its longest chains, split blocks with the
+ *                        look-ahead walker on the other CUs (value < 0: without it); 0 (default): all wide, two blocks per CU, which
+ *                        is faster.  (gact_hip_run_stats with the mix: layout split, critical_lane 1)
+ *   "shared_twelfths"    a linear-gap main launch that shares the machine and has more chains than two thirds of the resident tile slots
+ *                        hold takes value / 12 of the resident blocks (default 6)
  *   "overlap_big"        1: ordered, overlapped seeding also for runs of more than four chains per resident tile slot (seed launch A
  *                        takes the longest eighth of the list, B the rest beside main launch 1); 0 (default): seed launch, then one
  *                        main launch
@@ -330,7 +332,8 @@ int64_t gact_hip_options_describe(char *buf, int64_t cap);
 /* The launch plan -- sequence, kernels, grids -- that an engine of parameters p makes for one pass over `count` candidates on a
  * device of compute_units CUs (kernels at their nominal occupancy), as one JSON object.  flags: bit 0 = the read sets hold
  * bytes other than A/C/G/T, bit 1 = the launch shares the machine (other runs in flight), bit 2 = role launch on, bit 3 =
- * cooperative launch always, bit 4 = never (neither: where the policy takes it).
+ * cooperative launch always, bit 4 = never (neither: where the policy takes it), bit 5 = "overlap_big" 1, bit 6 = "lone_lane" 48
+ * (the two optional sequences of gact_hip_set_option).
  * The policy is a pure function (csrc/gact_policy.hpp); this entry exists so that it can be swept and tested without a
  * device.  Same buffer convention as gact_hip_options_describe. */
 int64_t gact_hip_plan_describe(const gact_hip_params *p, int32_t compute_units, int32_t count, int32_t flags, char *buf, int64_t cap);
